@@ -1,0 +1,34 @@
+"""pytest configuration: the `gpu` marker and shared paths/fixtures."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "tests") not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def manifest():
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    """golden(name) -> float32 array (n, 8) of a committed fixture file."""
+
+    def load(name):
+        return np.fromfile(os.path.join(GOLDEN, name), dtype=np.float32).reshape(-1, 8)
+
+    return load
