@@ -1,0 +1,154 @@
+/*
+ * nbody_hip.h -- C-ABI of the HIP/gfx950 simulation pipeline (libnbody_hip.so).
+ *
+ * This is the drop-in boundary.  Part 1 is, symbol for symbol, the seam the
+ * reference's world layer calls into its Vulkan backend through
+ * (reference src/lib/sim_gpu.h:8-42, called from src/lib/world.c:52,69,78,86,115):
+ * a maintainer deletes src/lib/sim_gpu.c, src/lib/vulkan_ctx.c and
+ * src/shader/particle_cs.glsl, links this library, and world.c is unchanged
+ * (INTEGRATION.md shows it; oracle/_ref/libnbody_ref_world.so is exactly that
+ * build).  Part 2 adds what a single-queue Vulkan backend had no notion of:
+ * device-resident stepping, kernel timing, and the N/P sharded multi-GPU
+ * pipeline with its per-step all-gather of source positions over RCCL.
+ *
+ * Plain C types only; no HIP, RCCL or torch types cross this boundary.
+ * Error convention = the reference's (src/lib/util.h:17-29,47-60): any failure
+ * prints "file:line [func] ..." to stderr and abort()s.  There is NO CPU
+ * fallback: a call that needs the GPU aborts when no gfx950 device answers.
+ */
+#ifndef NBODY_AMD_NBODY_HIP_H
+#define NBODY_AMD_NBODY_HIP_H
+
+#include <stdint.h>
+#include "nbody.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* Part 1: the reference seam (src/lib/sim_gpu.h)                             */
+/* ------------------------------------------------------------------------- */
+
+/* Sizes of a world and its step; replaces reference sim_gpu.h:8-12 (the uniform block). */
+typedef struct WorldData {
+    uint32_t total_len; /* all particles */
+    uint32_t mass_len;  /* particles with mass > 0; they come first */
+    float dt;           /* cached step size; PerformSimUpdate's dt wins */
+} WorldData;
+
+/* One world's device state + launch machinery; replaces reference sim_gpu.h:15. */
+typedef struct SimPipeline SimPipeline;
+
+/*
+ * Replaces reference sim_gpu.h:21 (CreateSimPipeline, sim_gpu.c:34-221).
+ * Allocates nothing on the GPU yet: device selection, HBM buffers and graphs are
+ * made at the first SetSimulationData, so a World used only through
+ * UpdateWorld_CPU never touches a GPU (SURVEY.md 8b "init side effects").
+ */
+SimPipeline *CreateSimPipeline(WorldData data);
+
+/* Replaces reference sim_gpu.h:24 (sim_gpu.c:223-247). NULL is accepted. */
+void DestroySimPipeline(SimPipeline *sim);
+
+/*
+ * Replaces reference sim_gpu.h:27 (sim_gpu.c:249-251): writes total_len
+ * Particles (AoS, partitioned order) holding the device's latest state into ps.
+ * Here this is where the D2H copy happens (the reference pays it after every
+ * PerformSimUpdate, sim_gpu.c:336-341).
+ */
+void GetSimulationData(const SimPipeline *sim, Particle *ps);
+
+/*
+ * Replaces reference sim_gpu.h:30 (sim_gpu.c:253-256): uploads total_len
+ * Particles (AoS, already partitioned: ps[i].mass > 0 exactly for i < mass_len)
+ * and splits them into the SoA streams the kernels read.
+ */
+void SetSimulationData(SimPipeline *sim, const Particle *ps);
+
+/*
+ * Replaces reference sim_gpu.h:36 (sim_gpu.c:258-361): n > 0 steps of size dt,
+ * blocking.  Simulation data must have been set.  n == 0 is a no-op here
+ * (the reference documents n > 0; world.c:113 never passes 0).
+ */
+void PerformSimUpdate(SimPipeline *sim, uint32_t n, float dt);
+
+/* ------------------------------------------------------------------------- */
+/* Part 2: extensions (no reference counterpart)                              */
+/* ------------------------------------------------------------------------- */
+
+/* Number of visible HIP devices; 0 when there is none.  Never aborts. */
+int nb_hip_device_count(void);
+
+/* Device ordinal this process' pipelines are created on (default: 0, or LOCAL_RANK for sharded ones). */
+void nb_hip_set_device(int ordinal);
+
+/* Fills buf (NUL-terminated, at most len bytes) with "name arch CUs clockMHz"; aborts without a GPU. */
+void nb_hip_device_info(char *buf, uint32_t len);
+
+/* PerformSimUpdate without the final host wait: enqueue n steps and return. */
+void nb_hip_step_async(SimPipeline *sim, uint32_t n, float dt);
+
+/* Wait for everything enqueued on the pipeline's stream(s). */
+void nb_hip_sync(SimPipeline *sim);
+
+/*
+ * Device time, in milliseconds, of the force+integrate kernels of the most
+ * recent PerformSimUpdate / nb_hip_step_async (HIP events recorded on the
+ * launch stream around the step chain; waits for them).  *launches receives the
+ * number of step-kernel launches those events bracket.
+ */
+double nb_hip_last_step_ms(SimPipeline *sim, uint32_t *launches);
+
+/*
+ * Tuning knobs.  key is one of:
+ *   "variant"   0 = wave-private LDS tiles (default), 1 = scalar-cache (SMEM) source broadcast
+ *   "k"         receivers per lane: 0 = auto, else 1, 2 or 4
+ *   "w"         waves (source slices) per workgroup: 0 = auto, else 1, 2, 4, 8 or 16
+ *   "graph"     1 = run step chains as hipGraphs (default), 0 = plain stream launches
+ *   "overlap"   sharded pipelines: 1 = split each step into own-shard / remote-shard kernels
+ *               with the all-gather in between on a second stream, 0 = gather then one kernel
+ * Returns the previous value; aborts on an unknown key or value.
+ */
+int nb_hip_configure(SimPipeline *sim, const char *key, int value);
+
+/* What the last step launch actually used (after "auto"): fills k, w, variant, workgroups. */
+void nb_hip_launch_shape(const SimPipeline *sim, int *k, int *w, int *variant, uint32_t *workgroups);
+
+/* -- sharded (multi-GPU) pipeline: one process per GPU, N/P receivers each -- */
+
+#define NB_HIP_UNIQUE_ID_BYTES 128
+
+/* Rank 0 calls this and ships the 128 bytes to every rank (any transport). Wraps ncclGetUniqueId. */
+void nb_hip_comm_unique_id(void *out128);
+
+/*
+ * Collective over all ranks.  Each rank passes the same WorldData and later the
+ * same full particle array; rank r owns the r-th 1/P slice of the massive range
+ * and the r-th 1/P slice of the massless range (nb_hip_shard_plan).
+ * SetSimulationData / PerformSimUpdate / GetSimulationData keep their meaning and
+ * become collectives: Get returns the FULL array on every rank.
+ */
+SimPipeline *CreateSimPipelineSharded(WorldData data, int rank, int nranks, const void *unique_id128);
+
+/* The shard arithmetic, pure host code (usable without a GPU). */
+typedef struct NbShardPlan {
+    uint32_t mass_chunk;   /* Mc: massive slots per rank (uniform, padded)             */
+    uint32_t zero_chunk;   /* Zc: massless slots per rank (uniform, padded)            */
+    uint32_t mass_begin;   /* first global massive index owned: rank * Mc, clamped      */
+    uint32_t mass_count;   /* owned massive particles (<= Mc)                           */
+    uint32_t zero_begin;   /* first global massless index owned (>= mass_len), clamped  */
+    uint32_t zero_count;   /* owned massless particles (<= Zc)                          */
+    uint32_t src_padded;   /* nranks * Mc: length of the gathered source array          */
+} NbShardPlan;
+
+NbShardPlan nb_hip_shard_plan(uint32_t total_len, uint32_t mass_len, int rank, int nranks);
+
+/* Library/ABI version: major*10000 + minor*100 + patch. */
+int nb_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* NBODY_AMD_NBODY_HIP_H */

@@ -1,0 +1,237 @@
+"""nbody_amd -- Python view of the MI355X-native N-body engine (for tests, bench.py and tooling).
+
+The product is C: `lib/libnbody_hip.so` (HIP kernels + the C-ABI of include/nbody_hip.h) and
+`lib/libnbody.so` (the include/nbody.h / galaxy.h surface, C host code).  This module only binds
+them with ctypes; no arithmetic happens in Python and there is no fallback: if the libraries are
+missing, importing the bound functions raises, and any GPU call without a gfx950 device aborts
+inside the library (reference error convention, src/lib/util.h:17-29).
+
+Particles travel as float32 arrays of shape (n, 8): pos.xy vel.xy acc.xy mass radius --
+byte-identical to `Particle[n]` (include/nbody.h).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+HIP_SO = os.path.join(LIB_DIR, "libnbody_hip.so")
+NBODY_SO = os.path.join(LIB_DIR, "libnbody.so")
+
+NB_G = 10.0
+UNIQUE_ID_BYTES = 128
+
+
+class WorldData(C.Structure):
+    """include/nbody_hip.h WorldData (reference src/lib/sim_gpu.h:8-12)."""
+    _fields_ = [("total_len", C.c_uint32), ("mass_len", C.c_uint32), ("dt", C.c_float)]
+
+
+class NbShardPlan(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("mass_chunk", "zero_chunk", "mass_begin", "mass_count",
+                                          "zero_begin", "zero_count", "src_padded")]
+
+
+# every symbol include/nbody_hip.h declares: (restype, argtypes)
+HIP_API = {
+    "CreateSimPipeline": (C.c_void_p, [WorldData]),
+    "DestroySimPipeline": (None, [C.c_void_p]),
+    "GetSimulationData": (None, [C.c_void_p, C.c_void_p]),
+    "SetSimulationData": (None, [C.c_void_p, C.c_void_p]),
+    "PerformSimUpdate": (None, [C.c_void_p, C.c_uint32, C.c_float]),
+    "nb_hip_device_count": (C.c_int, []),
+    "nb_hip_set_device": (None, [C.c_int]),
+    "nb_hip_device_info": (None, [C.c_char_p, C.c_uint32]),
+    "nb_hip_step_async": (None, [C.c_void_p, C.c_uint32, C.c_float]),
+    "nb_hip_sync": (None, [C.c_void_p]),
+    "nb_hip_last_step_ms": (C.c_double, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "nb_hip_configure": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "nb_hip_launch_shape": (None, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_uint32)]),
+    "nb_hip_comm_unique_id": (None, [C.c_void_p]),
+    "CreateSimPipelineSharded": (C.c_void_p, [WorldData, C.c_int, C.c_int, C.c_void_p]),
+    "nb_hip_shard_plan": (NbShardPlan, [C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
+    "nb_hip_version": (C.c_int, []),
+}
+
+# include/nbody.h + include/galaxy.h
+NBODY_API = {
+    "CreateWorld": (C.c_void_p, [C.c_void_p, C.c_uint32]),
+    "DestroyWorld": (None, [C.c_void_p]),
+    "GetWorldParticles": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "UpdateWorld_CPU": (None, [C.c_void_p, C.c_float, C.c_uint32]),
+    "UpdateWorld_GPU": (None, [C.c_void_p, C.c_float, C.c_uint32]),
+    "MakeGalaxies": (C.c_void_p, [C.c_uint32, C.c_uint32]),
+}
+
+_hip = None
+_nbody = None
+
+
+def _bind(lib, api):
+    for name, (res, args) in api.items():
+        f = getattr(lib, name)  # AttributeError if the library does not export it
+        f.restype = res
+        f.argtypes = args
+    return lib
+
+
+def hip_lib():
+    """libnbody_hip.so, loaded once.  Raises OSError when it has not been built."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_SO):
+            raise OSError(f"{HIP_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _hip = _bind(C.CDLL(HIP_SO, mode=C.RTLD_GLOBAL), HIP_API)
+    return _hip
+
+
+def nbody_lib():
+    """libnbody.so (World API), loaded once; pulls libnbody_hip.so in first."""
+    global _nbody
+    if _nbody is None:
+        hip_lib()
+        if not os.path.exists(NBODY_SO):
+            raise OSError(f"{NBODY_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _nbody = _bind(C.CDLL(NBODY_SO, mode=C.RTLD_GLOBAL), NBODY_API)
+    return _nbody
+
+
+def as_particles(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] != 8:
+        raise ValueError("particles must have shape (n, 8)")
+    return a
+
+
+def device_count():
+    return int(hip_lib().nb_hip_device_count())
+
+
+def device_info():
+    buf = C.create_string_buffer(256)
+    hip_lib().nb_hip_device_info(buf, 256)
+    return buf.value.decode()
+
+
+def shard_plan(total_len, mass_len, rank, nranks):
+    p = hip_lib().nb_hip_shard_plan(total_len, mass_len, rank, nranks)
+    return {n: int(getattr(p, n)) for n, _ in NbShardPlan._fields_}
+
+
+def comm_unique_id():
+    buf = (C.c_ubyte * UNIQUE_ID_BYTES)()
+    hip_lib().nb_hip_comm_unique_id(buf)
+    return bytes(buf)
+
+
+class SimPipeline:
+    """The inner seam (reference src/lib/sim_gpu.h:21-36) as an object.
+
+    `particles` passed to set_data must already be partitioned (mass > 0 first) with
+    `mass_len` massive ones, exactly what reference src/lib/world.c:32-58 hands its backend.
+    """
+
+    def __init__(self, total_len, mass_len, rank=0, nranks=1, unique_id=None):
+        L = hip_lib()
+        wd = WorldData(total_len, mass_len, 0.0)
+        if nranks > 1:
+            idbuf = (C.c_ubyte * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+            self._h = L.CreateSimPipelineSharded(wd, rank, nranks, idbuf)
+        else:
+            self._h = L.CreateSimPipeline(wd)
+        self.total_len, self.mass_len = total_len, mass_len
+        self.rank, self.nranks = rank, nranks
+
+    def close(self):
+        if self._h:
+            hip_lib().DestroySimPipeline(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_data(self, particles):
+        a = as_particles(particles)
+        assert a.shape[0] == self.total_len
+        hip_lib().SetSimulationData(self._h, a.ctypes.data)
+
+    def get_data(self):
+        out = np.empty((self.total_len, 8), dtype=np.float32)
+        hip_lib().GetSimulationData(self._h, out.ctypes.data)
+        return out
+
+    def update(self, n, dt):
+        """Blocking n steps (PerformSimUpdate)."""
+        hip_lib().PerformSimUpdate(self._h, n, dt)
+
+    def step_async(self, n, dt):
+        hip_lib().nb_hip_step_async(self._h, n, dt)
+
+    def sync(self):
+        hip_lib().nb_hip_sync(self._h)
+
+    def last_step_ms(self):
+        launches = C.c_uint32(0)
+        ms = hip_lib().nb_hip_last_step_ms(self._h, C.byref(launches))
+        return float(ms), int(launches.value)
+
+    def configure(self, **knobs):
+        for k, v in knobs.items():
+            hip_lib().nb_hip_configure(self._h, k.encode(), int(v))
+
+    def launch_shape(self):
+        k, w, v, g = C.c_int(), C.c_int(), C.c_int(), C.c_uint32()
+        hip_lib().nb_hip_launch_shape(self._h, C.byref(k), C.byref(w), C.byref(v), C.byref(g))
+        return {"k": k.value, "w": w.value, "variant": "smem" if v.value else "lds", "workgroups": g.value}
+
+
+class World:
+    """include/nbody.h World, bound 1:1 (CreateWorld / UpdateWorld_CPU / UpdateWorld_GPU / ...)."""
+
+    def __init__(self, particles):
+        a = as_particles(particles)
+        self.size = a.shape[0]
+        self._h = nbody_lib().CreateWorld(a.ctypes.data, self.size)
+
+    def close(self):
+        if self._h:
+            nbody_lib().DestroyWorld(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def particles(self):
+        n = C.c_uint32(0)
+        p = nbody_lib().GetWorldParticles(self._h, C.byref(n))
+        if n.value == 0:
+            return np.empty((0, 8), dtype=np.float32)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n.value, 8)).copy()
+
+    def update_cpu(self, dt, n):
+        nbody_lib().UpdateWorld_CPU(self._h, dt, n)
+
+    def update_gpu(self, dt, n):
+        nbody_lib().UpdateWorld_GPU(self._h, dt, n)
+
+
+def make_galaxies(particle_count, galaxy_count, seed=None):
+    """include/galaxy.h MakeGalaxies; `seed` calls libc srand first (bench.c:42 uses 11037)."""
+    L = nbody_lib()
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    if seed is not None:
+        libc.srand(C.c_uint(seed))
+    p = L.MakeGalaxies(particle_count, galaxy_count)
+    a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(particle_count, 8)).copy()
+    libc.free(p)
+    return a

@@ -1,0 +1,72 @@
+// kernels.h -- internal (C++) launch interface between the pipeline and the gfx950 kernels.
+// Not part of the C-ABI; include/nbody_hip.h is.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nb {
+
+enum : uint32_t {
+    STEP_ACC_IN = 1u,       // start each receiver's sum from acc[] instead of zero
+    STEP_NO_FINALIZE = 2u,  // store the sums into acc[] and skip the integrator
+};
+
+enum : int {
+    VARIANT_LDS = 0,   // wave-private LDS tiles (coalesced float2 loads -> ds_write -> broadcast ds_read_b128)
+    VARIANT_SMEM = 1,  // wave-uniform source loads through the scalar cache (s_load_dwordx8/16)
+};
+
+// Everything one force(+integrate) launch needs.  Passed by value as the single kernel argument,
+// so a hipGraph kernel node is re-pointed by rewriting one struct.
+struct StepParams {
+    // sources = snapshot of the previous step (Jacobi): positions and premultiplied G*m
+    const float2 *src_pos;
+    const float *src_gm;
+    uint32_t src_begin[2];  // two half-open source ranges, walked back to back;
+    uint32_t src_end[2];    // the second is empty except in the overlapped sharded step
+    // receivers owned by this launch
+    const float2 *pos_in;
+    float2 *pos_out;
+    float2 *vel;
+    float2 *acc;
+    const float *radius;
+    uint32_t n_recv;
+    // new positions of receivers [0, n_mirror) are also written here (the shard's slice of the
+    // next gathered source array); n_mirror == 0 disables it
+    float2 *mirror;
+    uint32_t n_mirror;
+    float dt;
+    uint32_t flags;
+};
+
+struct LaunchShape {
+    int k;        // receivers per lane: 1, 2, 4
+    int w;        // waves per workgroup = source slices: 1, 2, 4, 8, 16
+    int variant;  // VARIANT_*
+};
+
+// Resolve "auto" (0) entries of `want` for a launch over n_recv receivers.
+LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, int compute_units);
+
+// Kernel entry point and grid for a shape; used both for direct launches and for graph nodes.
+const void *step_kernel_fn(LaunchShape s);
+dim3 step_grid(LaunchShape s, uint32_t n_recv);
+dim3 step_block(LaunchShape s);
+
+// AoS <-> SoA converters (reference Particle layout, include/nbody.h).
+// split: aos[first .. first+count) -> soa slots [slot0 .. slot0+count); gm = NB_G * mass
+void launch_split(hipStream_t st, const void *aos, uint32_t first, uint32_t count, float2 *pos, float2 *vel, float2 *acc,
+                  float *radius, float *mass, uint32_t slot0);
+// fill pad slots so that they are inert sources / harmless receivers
+void launch_fill_pad(hipStream_t st, float2 *pos, float2 *vel, float2 *acc, float *radius, float *mass, uint32_t slot0,
+                     uint32_t count);
+// gm[j] = NB_G * mass[j] for j < count (0 where mass <= 0)
+void launch_make_gm(hipStream_t st, const float *mass, float *gm, uint32_t count);
+// merge: soa slots [slot0 .. slot0+count) -> aos[first .. first+count)
+void launch_merge(hipStream_t st, void *aos, uint32_t first, uint32_t count, const float2 *pos, const float2 *vel,
+                  const float2 *acc, const float *radius, const float *mass, uint32_t slot0);
+// dst[i] = src[i] for float2 (device-side copy kernel usable inside graphs)
+void launch_copy_f2(hipStream_t st, float2 *dst, const float2 *src, uint32_t count);
+
+}  // namespace nb

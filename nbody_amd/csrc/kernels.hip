@@ -1,0 +1,342 @@
+// kernels.hip -- gfx950 (CDNA4, wave64) kernels of the direct N-body step.
+//
+// Replaces the reference's GLSL compute shader (reference src/shader/particle_cs.glsl:28-55), which
+// walks all sources per thread straight from global memory as 32-byte AoS records.  Here:
+//
+//   * one LANE owns K receivers (register blocking), one WAVE owns 64*K receivers and a 1/W slice of the
+//     sources, one WORKGROUP = W waves over the same 64*K receivers; the W partial sums meet in LDS in a
+//     fixed order (deterministic results), then the workgroup integrates and stores;
+//   * sources reach the VALU wave-uniformly, 12 bytes each (x, y, G*m), by one of two routes:
+//       VARIANT_LDS   each wave stages 64-source tiles in its own LDS slab: coalesced float2/float loads
+//                     (one source per lane), ds_write, then broadcast ds_read_b128 of 4 sources per
+//                     component; double-buffered, no workgroup barrier in the loop;
+//       VARIANT_SMEM  the wave reads its slice through the scalar cache (s_load_dwordx8/x16) so sources
+//                     arrive in SGPRs and feed the VALU as scalar operands; no LDS, no VGPR staging;
+//   * per interaction: 2 sub, 2 fma (dist^2 + receiver radius), v_rsq_f32, 3 mul, 2 fma = 10 VALU issues
+//     against the reference's 14 counted flops (SURVEY.md 8d keeps 14 as the roofline convention);
+//   * the integrator keeps the reference's rounding (mul, then add; sim_cpu.c:191-193 /
+//     particle_cs.glsl:51-52), the force loop does not (rsq + fma instead of sqrt, div, mul, add):
+//     DESIGN.md states the tolerance.
+//
+// fp32 throughout.  No MFMA: the loop is rsqrt/fma on independent (receiver, source) pairs, not a contraction.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace nb {
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int CHUNK = 64;  // sources per staged tile = one per lane
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v8f __attribute__((ext_vector_type(8)));
+
+template <int K>
+struct Receivers {
+    float x[K], y[K], r[K];
+    float ax[K], ay[K];
+};
+
+// One source against the K receivers of this lane.  sx/sy/sg are wave-uniform.
+template <int K>
+__device__ __forceinline__ void interact(Receivers<K> &R, float sx, float sy, float sg) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const float dx = sx - R.x[k];
+        const float dy = sy - R.y[k];
+        float d2 = __builtin_fmaf(dx, dx, R.r[k]);  // softening: + radius of the RECEIVER, not squared
+        d2 = __builtin_fmaf(dy, dy, d2);
+        const float inv = __builtin_amdgcn_rsqf(d2);  // v_rsq_f32, 1 ulp
+        const float inv2 = inv * inv;
+        const float gi = sg * inv;
+        const float f = gi * inv2;  // G*m / dist^3
+        R.ax[k] = __builtin_fmaf(dx, f, R.ax[k]);
+        R.ay[k] = __builtin_fmaf(dy, f, R.ay[k]);
+    }
+}
+
+// Map a position v of the concatenated source ranges to an index of src_pos/src_gm.
+__device__ __forceinline__ uint32_t source_index(const StepParams &p, uint32_t v, uint32_t n0) {
+    return v < n0 ? p.src_begin[0] + v : p.src_begin[1] + (v - n0);
+}
+
+template <int K, int W, int VARIANT>
+__global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (WAVE - 1);
+    // wave id as an SGPR value so that everything derived from it stays scalar
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t recv_base = blockIdx.x * (WAVE * K);
+
+    __shared__ __attribute__((aligned(16))) float tile[VARIANT == VARIANT_LDS ? W : 1][2][3][CHUNK];
+    __shared__ float2 partial[W > 1 ? W : 1][W > 1 ? WAVE * K : 1];
+
+    Receivers<K> R;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        uint32_t i = recv_base + k * WAVE + lane;
+        i = i < p.n_recv ? i : p.n_recv - 1;  // tail lanes redo the last receiver; their stores are masked
+        const float2 q = p.pos_in[i];
+        R.x[k] = q.x;
+        R.y[k] = q.y;
+        R.r[k] = p.radius[i];
+        R.ax[k] = 0.0f;
+        R.ay[k] = 0.0f;
+    }
+
+    // this wave's slice of the concatenated source ranges, in whole chunks
+    const uint32_t n0 = p.src_end[0] - p.src_begin[0];
+    const uint32_t n1 = p.src_end[1] - p.src_begin[1];
+    const uint32_t total = n0 + n1;
+    const uint32_t nchunks = (total + CHUNK - 1) / CHUNK;
+    const uint32_t per_wave = (nchunks + W - 1) / W;
+    const uint32_t c_lo = min(wid * per_wave, nchunks);
+    const uint32_t c_hi = min(c_lo + per_wave, nchunks);
+
+    if constexpr (VARIANT == VARIANT_LDS) {
+        float(*T)[3][CHUNK] = tile[wid];
+        float2 sp = make_float2(0.f, 0.f);
+        float sg = 0.f;
+        auto fetch = [&](uint32_t c) {
+            const uint32_t v = c * CHUNK + lane;
+            const bool live = v < total;
+            const uint32_t j = source_index(p, live ? v : total - 1, n0);
+            sp = p.src_pos[j];                 // 512 B per wave, coalesced
+            sg = live ? p.src_gm[j] : 0.0f;    // pad sources: a real position, zero mass
+        };
+        if (c_lo < c_hi) fetch(c_lo);
+        int buf = 0;
+        for (uint32_t c = c_lo; c < c_hi; c++) {
+            T[buf][0][lane] = sp.x;
+            T[buf][1][lane] = sp.y;
+            T[buf][2][lane] = sg;
+            if (c + 1 < c_hi) fetch(c + 1);  // next tile's HBM/L2 latency hides under this tile's math
+            // LDS executes one wave's accesses in order; this only stops the compiler from reordering
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 2
+            for (int jj = 0; jj < CHUNK; jj += 4) {
+                const float4 X = *reinterpret_cast<const float4 *>(&T[buf][0][jj]);  // broadcast ds_read_b128
+                const float4 Y = *reinterpret_cast<const float4 *>(&T[buf][1][jj]);
+                const float4 G = *reinterpret_cast<const float4 *>(&T[buf][2][jj]);
+                interact<K>(R, X.x, Y.x, G.x);
+                interact<K>(R, X.y, Y.y, G.y);
+                interact<K>(R, X.z, Y.z, G.z);
+                interact<K>(R, X.w, Y.w, G.w);
+            }
+            buf ^= 1;
+        }
+    } else {
+        // scalar-cache route: indices are wave-uniform, the loads become s_load_dwordx8/x16
+        const uint32_t v_lo = c_lo * CHUNK;
+        const uint32_t v_hi = min(c_hi * CHUNK, total);
+#pragma unroll
+        for (int range = 0; range < 2; range++) {
+            // intersection of [v_lo, v_hi) with this range, as indices of the source arrays
+            const uint32_t r_lo = range == 0 ? 0u : n0;
+            const uint32_t r_hi = range == 0 ? n0 : total;
+            const uint32_t a = max(v_lo, r_lo), b = min(v_hi, r_hi);
+            if (a >= b) continue;
+            uint32_t j = p.src_begin[range] + (a - r_lo);
+            const uint32_t j_end = p.src_begin[range] + (b - r_lo);
+            // 8 sources per scalar fetch: s_load_dwordx16 (x,y pairs) + s_load_dwordx8 (G*m).  Slices start on
+            // multiples of 64 sources from 64-aligned range starts, so j is a multiple of 8 here.
+            const float *__restrict__ sp = reinterpret_cast<const float *>(p.src_pos);
+            const float *__restrict__ sg = p.src_gm;
+            const uint32_t groups = (j_end - j) / 8;
+            if (groups > 0) {
+                v16f P = *reinterpret_cast<const v16f *>(sp + 2 * (size_t)j);
+                v8f G = *reinterpret_cast<const v8f *>(sg + j);
+                for (uint32_t g = 0; g < groups; g++) {
+                    const v16f Pc = P;
+                    const v8f Gc = G;
+                    j += 8;
+                    if (g + 1 < groups) {  // next group's scalar-cache latency hides under this group's math
+                        P = *reinterpret_cast<const v16f *>(sp + 2 * (size_t)j);
+                        G = *reinterpret_cast<const v8f *>(sg + j);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) interact<K>(R, Pc[2 * u], Pc[2 * u + 1], Gc[u]);
+                }
+            }
+            for (; j < j_end; j++) interact<K>(R, sp[2 * (size_t)j], sp[2 * (size_t)j + 1], sg[j]);
+        }
+    }
+
+    // ---- combine the W slices in wave order, integrate, store -------------------------------------------
+    auto finish = [&](uint32_t i, float sx, float sy) {
+        if (i >= p.n_recv) return;
+        float2 a = make_float2(sx, sy);
+        if (p.flags & STEP_ACC_IN) {
+            const float2 a0 = p.acc[i];
+            a.x = __fadd_rn(a0.x, a.x);
+            a.y = __fadd_rn(a0.y, a.y);
+        }
+        p.acc[i] = a;
+        if (p.flags & STEP_NO_FINALIZE) return;
+        // semi-implicit Euler with the reference's roundings: vel += acc*dt; pos += vel*dt
+        float2 v = p.vel[i];
+        v.x = __fadd_rn(v.x, __fmul_rn(a.x, p.dt));
+        v.y = __fadd_rn(v.y, __fmul_rn(a.y, p.dt));
+        float2 q = p.pos_in[i];
+        q.x = __fadd_rn(q.x, __fmul_rn(v.x, p.dt));
+        q.y = __fadd_rn(q.y, __fmul_rn(v.y, p.dt));
+        p.vel[i] = v;
+        p.pos_out[i] = q;
+        if (i < p.n_mirror) p.mirror[i] = q;
+    };
+
+    if constexpr (W == 1) {
+#pragma unroll
+        for (int k = 0; k < K; k++) finish(recv_base + k * WAVE + lane, R.ax[k], R.ay[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; k++) partial[wid][k * WAVE + lane] = make_float2(R.ax[k], R.ay[k]);
+        __syncthreads();
+#pragma unroll
+        for (uint32_t slot = tid; slot < WAVE * K; slot += WAVE * W) {
+            float sx = 0.0f, sy = 0.0f;
+#pragma unroll
+            for (int s = 0; s < W; s++) {
+                const float2 t = partial[s][slot];
+                sx = __fadd_rn(sx, t.x);
+                sy = __fadd_rn(sy, t.y);
+            }
+            finish(recv_base + slot, sx, sy);
+        }
+    }
+}
+
+// ---- AoS <-> SoA ----------------------------------------------------------------------------------------
+
+struct alignas(16) ParticleRec {  // == Particle (include/nbody.h): pos vel | acc mass radius
+    float4 a, b;
+};
+
+__global__ void split_kernel(const ParticleRec *aos, uint32_t first, uint32_t count, float2 *pos, float2 *vel, float2 *acc,
+                             float *radius, float *mass, uint32_t slot0) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const ParticleRec r = aos[first + i];
+    pos[slot0 + i] = make_float2(r.a.x, r.a.y);
+    vel[slot0 + i] = make_float2(r.a.z, r.a.w);
+    acc[slot0 + i] = make_float2(r.b.x, r.b.y);
+    mass[slot0 + i] = r.b.z;
+    radius[slot0 + i] = r.b.w;
+}
+
+__global__ void merge_kernel(ParticleRec *aos, uint32_t first, uint32_t count, const float2 *pos, const float2 *vel,
+                             const float2 *acc, const float *radius, const float *mass, uint32_t slot0) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float2 q = pos[slot0 + i], v = vel[slot0 + i], a = acc[slot0 + i];
+    ParticleRec r;
+    r.a = make_float4(q.x, q.y, v.x, v.y);
+    r.b = make_float4(a.x, a.y, mass[slot0 + i], radius[slot0 + i]);
+    aos[first + i] = r;
+}
+
+__global__ void fill_pad_kernel(float2 *pos, float2 *vel, float2 *acc, float *radius, float *mass, uint32_t slot0,
+                                uint32_t count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    // far away, finite, massless: contributes exactly 0 as a source and stays finite as a receiver
+    pos[slot0 + i] = make_float2(1.0e15f, 1.0e15f);
+    vel[slot0 + i] = make_float2(0.f, 0.f);
+    acc[slot0 + i] = make_float2(0.f, 0.f);
+    radius[slot0 + i] = 1.0f;
+    mass[slot0 + i] = 0.0f;
+}
+
+__global__ void make_gm_kernel(const float *mass, float *gm, uint32_t count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float m = mass[i];
+    gm[i] = m > 0.0f ? __fmul_rn(m, 10.0f) : 0.0f;  // NB_G * m, rounded as the reference's `gm = m * g`
+}
+
+__global__ void copy_f2_kernel(float2 *dst, const float2 *src, uint32_t count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = src[i];
+}
+
+inline dim3 grid1d(uint32_t count) { return dim3((count + 255u) / 256u); }
+
+template <int VARIANT>
+const void *pick(int k, int w) {
+#define NB_CASE(KK, WW) \
+    if (k == KK && w == WW) return reinterpret_cast<const void *>(&step_kernel<KK, WW, VARIANT>);
+    NB_CASE(1, 1) NB_CASE(1, 2) NB_CASE(1, 4) NB_CASE(1, 8) NB_CASE(1, 16)
+    NB_CASE(2, 1) NB_CASE(2, 2) NB_CASE(2, 4) NB_CASE(2, 8) NB_CASE(2, 16)
+    NB_CASE(4, 1) NB_CASE(4, 2) NB_CASE(4, 4) NB_CASE(4, 8) NB_CASE(4, 16)
+#undef NB_CASE
+    return nullptr;
+}
+
+}  // namespace
+
+LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, int compute_units) {
+    LaunchShape s = want;
+    if (compute_units <= 0) compute_units = 256;
+    if (s.k == 0) {
+        // deepest register blocking that still leaves two workgroups per CU
+        s.k = 1;
+        for (int k = 4; k >= 1; k /= 2) {
+            const uint32_t groups = (n_recv + WAVE * k - 1) / (WAVE * k);
+            if (groups >= 2u * (uint32_t)compute_units) {
+                s.k = k;
+                break;
+            }
+        }
+    }
+    if (s.w == 0) {
+        // enough source slices that the chip holds ~8 waves per SIMD
+        const uint32_t groups = (n_recv + WAVE * s.k - 1) / (WAVE * s.k);
+        const uint32_t want_waves = 8u * 4u * (uint32_t)compute_units;
+        int w = 1;
+        while (w < 16 && groups * (uint32_t)w < want_waves) w *= 2;
+        s.w = w;
+    }
+    return s;
+}
+
+const void *step_kernel_fn(LaunchShape s) {
+    return s.variant == VARIANT_SMEM ? pick<VARIANT_SMEM>(s.k, s.w) : pick<VARIANT_LDS>(s.k, s.w);
+}
+
+dim3 step_grid(LaunchShape s, uint32_t n_recv) { return dim3((n_recv + WAVE * s.k - 1) / (WAVE * s.k)); }
+dim3 step_block(LaunchShape s) { return dim3(WAVE * s.w); }
+
+void launch_split(hipStream_t st, const void *aos, uint32_t first, uint32_t count, float2 *pos, float2 *vel, float2 *acc,
+                  float *radius, float *mass, uint32_t slot0) {
+    if (count == 0) return;
+    hipLaunchKernelGGL(split_kernel, grid1d(count), dim3(256), 0, st, static_cast<const ParticleRec *>(aos), first, count,
+                       pos, vel, acc, radius, mass, slot0);
+}
+
+void launch_fill_pad(hipStream_t st, float2 *pos, float2 *vel, float2 *acc, float *radius, float *mass, uint32_t slot0,
+                     uint32_t count) {
+    if (count == 0) return;
+    hipLaunchKernelGGL(fill_pad_kernel, grid1d(count), dim3(256), 0, st, pos, vel, acc, radius, mass, slot0, count);
+}
+
+void launch_make_gm(hipStream_t st, const float *mass, float *gm, uint32_t count) {
+    if (count == 0) return;
+    hipLaunchKernelGGL(make_gm_kernel, grid1d(count), dim3(256), 0, st, mass, gm, count);
+}
+
+void launch_merge(hipStream_t st, void *aos, uint32_t first, uint32_t count, const float2 *pos, const float2 *vel,
+                  const float2 *acc, const float *radius, const float *mass, uint32_t slot0) {
+    if (count == 0) return;
+    hipLaunchKernelGGL(merge_kernel, grid1d(count), dim3(256), 0, st, static_cast<ParticleRec *>(aos), first, count, pos,
+                       vel, acc, radius, mass, slot0);
+}
+
+void launch_copy_f2(hipStream_t st, float2 *dst, const float2 *src, uint32_t count) {
+    if (count == 0) return;
+    hipLaunchKernelGGL(copy_f2_kernel, grid1d(count), dim3(256), 0, st, dst, src, count);
+}
+
+}  // namespace nb

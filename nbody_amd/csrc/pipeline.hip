@@ -1,0 +1,693 @@
+// pipeline.hip -- the C-ABI of include/nbody_hip.h: device state, step chains as hipGraphs,
+// AoS<->SoA hand-over, and the N/P sharded pipeline with its per-step RCCL all-gather.
+//
+// Stands where the reference has src/lib/sim_gpu.c (SimPipeline, command-buffer recording,
+// staging copies) and src/lib/vulkan_ctx.c (device pick, allocator).  Differences by design:
+//   * SoA in HBM (float2 pos/vel/acc, float radius/mass, float G*m) instead of 32-byte AoS records;
+//   * ping-pong position buffers instead of a full device-to-device copy per step (sim_gpu.c:316-324);
+//   * the n-step chain is a cached hipGraph of n kernel nodes whose parameters are patched when dt or
+//     the ping-pong phase changes, instead of re-recording a command buffer per call (sim_gpu.c:262-344);
+//   * device-to-host copy only when GetSimulationData asks (the reference copies after every call,
+//     sim_gpu.c:336-341);
+//   * nothing is created on the GPU until SetSimulationData, so CPU-only worlds never touch a device.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "kernels.h"
+#include "nbody_hip.h"
+
+#define NB_HIP_VERSION 100  // 0.1.0
+
+// ---- error convention: print where, abort (reference src/lib/util.h:17-29,47-60) -------------------------
+
+#define NB_FAIL(...)                                                          \
+    do {                                                                      \
+        fprintf(stderr, "%s:%d [%s] ", __FILE__, __LINE__, __func__);         \
+        fprintf(stderr, __VA_ARGS__);                                         \
+        fprintf(stderr, "\n");                                                \
+        abort();                                                              \
+    } while (0)
+
+#define NB_ASSERT(COND, ...)               \
+    do {                                   \
+        if (!(COND)) NB_FAIL(__VA_ARGS__); \
+    } while (0)
+
+#define ASSERT_HIP(X, ...)                                                                              \
+    do {                                                                                                \
+        hipError_t nb_e_ = (X);                                                                         \
+        if (nb_e_ != hipSuccess) {                                                                      \
+            fprintf(stderr, "%s:%d [%s] hipError_t = %d, str = %s\n", __FILE__, __LINE__, __func__,     \
+                    (int)nb_e_, hipGetErrorString(nb_e_));                                              \
+            NB_FAIL(__VA_ARGS__);                                                                       \
+        }                                                                                               \
+    } while (0)
+
+// ---- RCCL, bound lazily (librccl is ~0.5 GB; single-GPU users never load it) ------------------------------
+
+namespace {
+
+typedef struct ncclComm *ncclComm_t;
+typedef struct {
+    char internal[NB_HIP_UNIQUE_ID_BYTES];
+} ncclUniqueId;
+enum { NCCL_FLOAT32 = 7 };  // ncclDataType_t value of ncclFloat32 (rccl.h)
+
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+Rccl &rccl() {
+    static Rccl r;
+    if (r.handle) return r;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (r.handle) break;
+    }
+    NB_ASSERT(r.handle, "cannot load librccl.so.1 (%s): the sharded pipeline needs RCCL", dlerror());
+#define NB_SYM(field, name)                                                \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, name));  \
+    NB_ASSERT(r.field, "librccl lacks %s", name)
+    NB_SYM(GetUniqueId, "ncclGetUniqueId");
+    NB_SYM(CommInitRank, "ncclCommInitRank");
+    NB_SYM(CommDestroy, "ncclCommDestroy");
+    NB_SYM(AllGather, "ncclAllGather");
+    NB_SYM(GetErrorString, "ncclGetErrorString");
+#undef NB_SYM
+    return r;
+}
+
+#define ASSERT_NCCL(X, ...)                                                                                   \
+    do {                                                                                                      \
+        int nb_r_ = (X);                                                                                      \
+        if (nb_r_ != 0) {                                                                                     \
+            fprintf(stderr, "%s:%d [%s] ncclResult_t = %d, str = %s\n", __FILE__, __LINE__, __func__, nb_r_,  \
+                    rccl().GetErrorString(nb_r_));                                                            \
+            NB_FAIL(__VA_ARGS__);                                                                             \
+        }                                                                                                     \
+    } while (0)
+
+// ---- process-wide device context (the reference keeps one global vulkan_ctx, vulkan_ctx.c:11) -------------
+
+struct DeviceCtx {
+    bool ready = false;
+    int ordinal = -1;  // -1: not chosen yet
+    int compute_units = 0;
+    char info[256] = {0};
+};
+
+DeviceCtx g_dev;
+int g_requested_ordinal = -1;
+
+void ensure_device() {
+    if (g_dev.ready) return;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    NB_ASSERT(e == hipSuccess && count > 0,
+              "no HIP device visible (hipGetDeviceCount: %s, count %d); the GPU path has no CPU fallback",
+              hipGetErrorString(e), count);
+    int ord = g_requested_ordinal >= 0 ? g_requested_ordinal : 0;
+    NB_ASSERT(ord < count, "device ordinal %d requested, %d visible", ord, count);
+    ASSERT_HIP(hipSetDevice(ord), "hipSetDevice(%d)", ord);
+    hipDeviceProp_t prop;
+    ASSERT_HIP(hipGetDeviceProperties(&prop, ord), "hipGetDeviceProperties(%d)", ord);
+    NB_ASSERT(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
+              "device %d is %s; this library ships gfx950 (MI355X) code objects only", ord, prop.gcnArchName);
+    g_dev.ordinal = ord;
+    g_dev.compute_units = prop.multiProcessorCount;
+    snprintf(g_dev.info, sizeof g_dev.info, "%s %s %d %d", prop.name[0] ? prop.name : "AMD-GPU", prop.gcnArchName,
+             prop.multiProcessorCount, prop.clockRate / 1000);
+    g_dev.ready = true;
+}
+
+template <typename T>
+T *dev_alloc(size_t count) {
+    T *p = nullptr;
+    if (count == 0) count = 1;
+    ASSERT_HIP(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)), "hipMalloc of %zu bytes", count * sizeof(T));
+    return p;
+}
+
+void dev_free(void *p) {
+    if (p) ASSERT_HIP(hipFree(p), "hipFree");
+}
+
+uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+// ---- a cached chain of step launches ------------------------------------------------------------------------
+
+struct StepGraph {
+    uint32_t n = 0;           // steps in the chain
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<hipGraphNode_t> nodes;  // one kernel node per launch, in order
+    std::vector<nb::StepParams> params; // what each node currently holds
+    int phase = -1;                     // which pos buffer the chain reads first
+    float dt = 0.0f;
+    nb::LaunchShape shape = {0, 0, 0};
+};
+
+}  // namespace
+
+struct SimPipeline {
+    WorldData data;
+    // sharding (nranks == 1: the whole world on one device)
+    int rank = 0, nranks = 1;
+    NbShardPlan plan;
+    ncclComm_t comm = nullptr;
+
+    bool on_device = false;  // buffers exist and hold data
+    uint32_t slots = 0;      // receiver slots on this device
+    uint32_t n_src = 0;      // sources every receiver sees (mass_len, or the padded gathered length)
+
+    // SoA streams (DESIGN.md "Layout in HBM")
+    float2 *pos[2] = {nullptr, nullptr};
+    float2 *vel = nullptr;
+    float2 *acc = nullptr;
+    float *radius = nullptr;
+    float *mass = nullptr;
+    float2 *src_pos[2] = {nullptr, nullptr};  // sharded only: gathered source positions (ping-pong)
+    float *src_gm = nullptr;
+    void *aos = nullptr;     // device AoS staging for Set/Get (whole world)
+    void *aos_shard = nullptr;  // sharded only: this rank's slice, uniform size
+    int cur = 0;             // pos[cur] is the latest state
+
+    hipStream_t stream = nullptr;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    hipEvent_t ev_local = nullptr, ev_gather = nullptr;
+    bool timed = false;
+    uint32_t timed_launches = 0;
+
+    // knobs
+    int want_variant = nb::VARIANT_LDS, want_k = 0, want_w = 0;
+    int use_graph = 1, overlap = 0;
+    nb::LaunchShape last_shape = {0, 0, 0};
+    uint32_t last_groups = 0;
+
+    std::vector<StepGraph> graphs;
+};
+
+namespace {
+
+constexpr uint32_t GRAPH_CHAIN_MAX = 64;  // longer requests replay an even-length chain
+
+void destroy_graph(StepGraph &g) {
+    if (g.exec) ASSERT_HIP(hipGraphExecDestroy(g.exec), "hipGraphExecDestroy");
+    if (g.graph) ASSERT_HIP(hipGraphDestroy(g.graph), "hipGraphDestroy");
+    g.exec = nullptr;
+    g.graph = nullptr;
+    g.nodes.clear();
+    g.params.clear();
+}
+
+void release_device(SimPipeline *s) {
+    if (!s->on_device) return;
+    ASSERT_HIP(hipStreamSynchronize(s->stream), "sync before release");
+    for (auto &g : s->graphs) destroy_graph(g);
+    s->graphs.clear();
+    for (int b = 0; b < 2; b++) {
+        dev_free(s->pos[b]);
+        if (s->nranks > 1) dev_free(s->src_pos[b]);
+        s->pos[b] = s->src_pos[b] = nullptr;
+    }
+    dev_free(s->vel);
+    dev_free(s->acc);
+    dev_free(s->radius);
+    dev_free(s->mass);
+    dev_free(s->src_gm);
+    dev_free(s->aos);
+    dev_free(s->aos_shard);
+    ASSERT_HIP(hipEventDestroy(s->ev_begin), "event");
+    ASSERT_HIP(hipEventDestroy(s->ev_end), "event");
+    ASSERT_HIP(hipEventDestroy(s->ev_local), "event");
+    ASSERT_HIP(hipEventDestroy(s->ev_gather), "event");
+    if (s->comm_stream) ASSERT_HIP(hipStreamDestroy(s->comm_stream), "stream");
+    ASSERT_HIP(hipStreamDestroy(s->stream), "stream");
+    s->on_device = false;
+}
+
+// First touch of the GPU for this pipeline: stream, events, HBM buffers.
+void materialize(SimPipeline *s) {
+    if (s->on_device) return;
+    ensure_device();
+    ASSERT_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "stream");
+    ASSERT_HIP(hipEventCreate(&s->ev_begin), "event");
+    ASSERT_HIP(hipEventCreate(&s->ev_end), "event");
+    ASSERT_HIP(hipEventCreateWithFlags(&s->ev_local, hipEventDisableTiming), "event");
+    ASSERT_HIP(hipEventCreateWithFlags(&s->ev_gather, hipEventDisableTiming), "event");
+
+    const uint32_t N = s->data.total_len, M = s->data.mass_len;
+    if (s->nranks == 1) {
+        s->slots = N;
+        s->n_src = M;
+    } else {
+        ASSERT_HIP(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking), "comm stream");
+        s->slots = s->plan.mass_chunk + s->plan.zero_chunk;
+        s->n_src = s->plan.src_padded;
+    }
+    const uint32_t cap = s->slots ? s->slots : 1;
+    for (int b = 0; b < 2; b++) s->pos[b] = dev_alloc<float2>(cap);
+    s->vel = dev_alloc<float2>(cap);
+    s->acc = dev_alloc<float2>(cap);
+    s->radius = dev_alloc<float>(cap);
+    s->mass = dev_alloc<float>(cap);
+    s->src_gm = dev_alloc<float>(s->n_src);
+    s->aos = dev_alloc<Particle>(N);
+    if (s->nranks == 1) {
+        // the first mass_len receivers ARE the sources: no separate source array
+        s->src_pos[0] = s->pos[0];
+        s->src_pos[1] = s->pos[1];
+    } else {
+        for (int b = 0; b < 2; b++) s->src_pos[b] = dev_alloc<float2>(s->n_src);
+        s->aos_shard = dev_alloc<Particle>((size_t)s->slots * (size_t)s->nranks);
+    }
+    s->on_device = true;
+}
+
+nb::LaunchShape resolve_shape(SimPipeline *s) {
+    nb::LaunchShape want = {s->want_k, s->want_w, s->want_variant};
+    nb::LaunchShape sh = nb::choose_shape(want, s->slots, g_dev.compute_units);
+    NB_ASSERT(nb::step_kernel_fn(sh) != nullptr, "no step kernel for k=%d w=%d variant=%d", sh.k, sh.w, sh.variant);
+    s->last_shape = sh;
+    s->last_groups = nb::step_grid(sh, s->slots).x;
+    return sh;
+}
+
+// Parameters of the single-kernel step that reads phase `in` and writes phase `in ^ 1`.
+nb::StepParams whole_step(const SimPipeline *s, int in, float dt) {
+    nb::StepParams p;
+    memset(&p, 0, sizeof p);
+    p.src_pos = s->src_pos[in];
+    p.src_gm = s->src_gm;
+    p.src_begin[0] = 0;
+    p.src_end[0] = s->n_src;
+    p.src_begin[1] = p.src_end[1] = 0;
+    p.pos_in = s->pos[in];
+    p.pos_out = s->pos[in ^ 1];
+    p.vel = s->vel;
+    p.acc = s->acc;
+    p.radius = s->radius;
+    p.n_recv = s->slots;
+    if (s->nranks > 1) {
+        p.mirror = s->src_pos[in ^ 1] + (size_t)s->rank * s->plan.mass_chunk;
+        p.n_mirror = s->plan.mass_chunk;
+    }
+    p.dt = dt;
+    p.flags = 0;
+    return p;
+}
+
+void launch_step(SimPipeline *s, nb::LaunchShape sh, const nb::StepParams &p, hipStream_t st) {
+    nb::StepParams copy = p;
+    void *args[] = {&copy};
+    ASSERT_HIP(hipLaunchKernel(nb::step_kernel_fn(sh), nb::step_grid(sh, s->slots), nb::step_block(sh), args, 0, st),
+               "step kernel launch (k=%d w=%d variant=%d, %u receivers)", sh.k, sh.w, sh.variant, s->slots);
+}
+
+// ---- single-device chains ------------------------------------------------------------------------------------
+
+StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchShape sh) {
+    StepGraph *g = nullptr;
+    for (auto &c : s->graphs)
+        if (c.n == n && c.shape.k == sh.k && c.shape.w == sh.w && c.shape.variant == sh.variant) g = &c;
+    if (!g) {
+        s->graphs.emplace_back();
+        g = &s->graphs.back();
+        g->n = n;
+        g->shape = sh;
+        g->dt = dt;
+        g->phase = s->cur;
+        ASSERT_HIP(hipGraphCreate(&g->graph, 0), "hipGraphCreate");
+        g->nodes.resize(n);
+        g->params.resize(n);
+        hipGraphNode_t prev = nullptr;
+        for (uint32_t i = 0; i < n; i++) {
+            g->params[i] = whole_step(s, (s->cur + i) & 1, dt);
+            void *args[] = {&g->params[i]};
+            hipKernelNodeParams kp;
+            memset(&kp, 0, sizeof kp);
+            kp.func = const_cast<void *>(nb::step_kernel_fn(sh));
+            kp.gridDim = nb::step_grid(sh, s->slots);
+            kp.blockDim = nb::step_block(sh);
+            kp.sharedMemBytes = 0;
+            kp.kernelParams = args;
+            kp.extra = nullptr;
+            ASSERT_HIP(hipGraphAddKernelNode(&g->nodes[i], g->graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp),
+                       "hipGraphAddKernelNode %u/%u", i, n);
+            prev = g->nodes[i];
+        }
+        ASSERT_HIP(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0), "hipGraphInstantiate (%u nodes)", n);
+        return g;
+    }
+    if (g->phase != s->cur || g->dt != dt) {
+        // the analogue of the reference re-uploading its uniform when dt changes (sim_gpu.c:268-284):
+        // patch the kernel nodes instead of rebuilding the graph
+        for (uint32_t i = 0; i < n; i++) {
+            g->params[i] = whole_step(s, (s->cur + i) & 1, dt);
+            void *args[] = {&g->params[i]};
+            hipKernelNodeParams kp;
+            memset(&kp, 0, sizeof kp);
+            kp.func = const_cast<void *>(nb::step_kernel_fn(sh));
+            kp.gridDim = nb::step_grid(sh, s->slots);
+            kp.blockDim = nb::step_block(sh);
+            kp.kernelParams = args;
+            ASSERT_HIP(hipGraphExecKernelNodeSetParams(g->exec, g->nodes[i], &kp), "hipGraphExecKernelNodeSetParams");
+        }
+        g->phase = s->cur;
+        g->dt = dt;
+    }
+    return g;
+}
+
+void enqueue_single(SimPipeline *s, uint32_t n, float dt) {
+    const nb::LaunchShape sh = resolve_shape(s);
+    if (!s->use_graph || n == 1) {
+        for (uint32_t i = 0; i < n; i++) {
+            launch_step(s, sh, whole_step(s, s->cur, dt), s->stream);
+            s->cur ^= 1;
+        }
+        return;
+    }
+    uint32_t left = n;
+    while (left > 0) {
+        // full chains have even length so that replaying them keeps the ping-pong phase
+        const uint32_t chunk = left > GRAPH_CHAIN_MAX ? GRAPH_CHAIN_MAX : left;
+        StepGraph *g = find_or_build_graph(s, chunk, dt, sh);
+        ASSERT_HIP(hipGraphLaunch(g->exec, s->stream), "hipGraphLaunch (%u steps)", chunk);
+        if (chunk & 1) s->cur ^= 1;
+        left -= chunk;
+    }
+}
+
+// ---- sharded chains --------------------------------------------------------------------------------------------
+
+void allgather_sources(SimPipeline *s, int buf, hipStream_t st) {
+    // in place: this rank's slice already sits at rank * Mc (written by the step kernel's mirror store)
+    const size_t per_rank = (size_t)s->plan.mass_chunk * 2;  // floats
+    float *base = reinterpret_cast<float *>(s->src_pos[buf]);
+    ASSERT_NCCL(rccl().AllGather(base + (size_t)s->rank * per_rank, base, per_rank, NCCL_FLOAT32, s->comm, st),
+                "ncclAllGather of %zu floats per rank", per_rank);
+}
+
+void enqueue_sharded(SimPipeline *s, uint32_t n, float dt) {
+    const nb::LaunchShape sh = resolve_shape(s);
+    const uint32_t Mc = s->plan.mass_chunk;
+    const uint32_t own_lo = (uint32_t)s->rank * Mc, own_hi = own_lo + Mc;
+    for (uint32_t i = 0; i < n; i++) {
+        const int in = s->cur;
+        if (!s->overlap) {
+            // gather(positions of step t) -> one kernel over all sources
+            launch_step(s, sh, whole_step(s, in, dt), s->stream);
+            allgather_sources(s, in ^ 1, s->stream);
+        } else {
+            // own-shard sources are already here: start on them while the other P-1 slices of
+            // src_pos[in] are still arriving on the comm stream, then finish with the remote ones
+            nb::StepParams a = whole_step(s, in, dt);
+            a.src_begin[0] = own_lo;
+            a.src_end[0] = own_hi;
+            a.flags = nb::STEP_NO_FINALIZE;
+            a.n_mirror = 0;
+            launch_step(s, sh, a, s->stream);
+            ASSERT_HIP(hipStreamWaitEvent(s->stream, s->ev_gather, 0), "wait gather");
+            nb::StepParams b = whole_step(s, in, dt);
+            b.src_begin[0] = 0;
+            b.src_end[0] = own_lo;
+            b.src_begin[1] = own_hi;
+            b.src_end[1] = s->n_src;
+            b.flags = nb::STEP_ACC_IN;
+            launch_step(s, sh, b, s->stream);
+            ASSERT_HIP(hipEventRecord(s->ev_local, s->stream), "record local");
+            ASSERT_HIP(hipStreamWaitEvent(s->comm_stream, s->ev_local, 0), "comm waits for the new slice");
+            allgather_sources(s, in ^ 1, s->comm_stream);
+            ASSERT_HIP(hipEventRecord(s->ev_gather, s->comm_stream), "record gather");
+        }
+        s->cur ^= 1;
+    }
+    if (s->overlap) ASSERT_HIP(hipStreamWaitEvent(s->stream, s->ev_gather, 0), "join comm stream");
+}
+
+void enqueue_steps(SimPipeline *s, uint32_t n, float dt) {
+    NB_ASSERT(s->on_device, "PerformSimUpdate before SetSimulationData");
+    if (s->slots == 0 || n == 0) return;
+    ASSERT_HIP(hipEventRecord(s->ev_begin, s->stream), "record begin");
+    if (s->nranks == 1)
+        enqueue_single(s, n, dt);
+    else
+        enqueue_sharded(s, n, dt);
+    ASSERT_HIP(hipEventRecord(s->ev_end, s->stream), "record end");
+    s->timed = true;
+    s->timed_launches = (s->nranks > 1 && s->overlap) ? 2 * n : n;
+    s->data.dt = dt;
+}
+
+}  // namespace
+
+// ============================================================================================================
+// C-ABI
+// ============================================================================================================
+
+extern "C" {
+
+int nb_hip_version(void) { return NB_HIP_VERSION; }
+
+int nb_hip_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+void nb_hip_set_device(int ordinal) {
+    NB_ASSERT(!g_dev.ready || g_dev.ordinal == ordinal, "device %d already in use, cannot switch to %d", g_dev.ordinal,
+              ordinal);
+    g_requested_ordinal = ordinal;
+}
+
+void nb_hip_device_info(char *buf, uint32_t len) {
+    ensure_device();
+    if (buf && len) snprintf(buf, len, "%s", g_dev.info);
+}
+
+NbShardPlan nb_hip_shard_plan(uint32_t total_len, uint32_t mass_len, int rank, int nranks) {
+    NB_ASSERT(nranks >= 1 && rank >= 0 && rank < nranks, "rank %d of %d", rank, nranks);
+    NB_ASSERT(mass_len <= total_len, "mass_len %u > total_len %u", mass_len, total_len);
+    NbShardPlan p;
+    const uint32_t P = (uint32_t)nranks, r = (uint32_t)rank;
+    const uint32_t Z = total_len - mass_len;
+    // uniform, wave-aligned chunks: every rank contributes the same count to the all-gather
+    p.mass_chunk = round_up((mass_len + P - 1) / P, 64);
+    p.zero_chunk = round_up((Z + P - 1) / P, 64);
+    if (mass_len == 0) p.mass_chunk = 0;
+    if (Z == 0) p.zero_chunk = 0;
+    const uint64_t mb = (uint64_t)r * p.mass_chunk;
+    p.mass_begin = mb < mass_len ? (uint32_t)mb : mass_len;
+    p.mass_count = mb < mass_len ? (mass_len - p.mass_begin < p.mass_chunk ? mass_len - p.mass_begin : p.mass_chunk) : 0;
+    const uint64_t zb = (uint64_t)r * p.zero_chunk;
+    p.zero_begin = mass_len + (zb < Z ? (uint32_t)zb : Z);
+    p.zero_count = zb < Z ? (Z - (uint32_t)zb < p.zero_chunk ? Z - (uint32_t)zb : p.zero_chunk) : 0;
+    p.src_padded = P * p.mass_chunk;
+    return p;
+}
+
+SimPipeline *CreateSimPipeline(WorldData data) {
+    NB_ASSERT(data.mass_len <= data.total_len, "mass_len %u > total_len %u", data.mass_len, data.total_len);
+    SimPipeline *s = new SimPipeline();
+    s->data = data;
+    s->plan = nb_hip_shard_plan(data.total_len, data.mass_len, 0, 1);
+    const char *v = getenv("NB_HIP_VARIANT");
+    if (v) s->want_variant = atoi(v) ? nb::VARIANT_SMEM : nb::VARIANT_LDS;
+    const char *k = getenv("NB_HIP_K");
+    if (k) s->want_k = atoi(k);
+    const char *w = getenv("NB_HIP_W");
+    if (w) s->want_w = atoi(w);
+    const char *gr = getenv("NB_HIP_GRAPH");
+    if (gr) s->use_graph = atoi(gr) ? 1 : 0;
+    return s;
+}
+
+void nb_hip_comm_unique_id(void *out128) {
+    NB_ASSERT(out128 != nullptr, "NULL id buffer");
+    ncclUniqueId id;
+    ASSERT_NCCL(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+    memcpy(out128, &id, NB_HIP_UNIQUE_ID_BYTES);
+}
+
+SimPipeline *CreateSimPipelineSharded(WorldData data, int rank, int nranks, const void *unique_id128) {
+    NB_ASSERT(nranks >= 1 && rank >= 0 && rank < nranks, "rank %d of %d", rank, nranks);
+    if (nranks == 1) return CreateSimPipeline(data);
+    NB_ASSERT(unique_id128 != nullptr, "sharded pipeline needs the RCCL unique id");
+    SimPipeline *s = CreateSimPipeline(data);
+    s->rank = rank;
+    s->nranks = nranks;
+    s->plan = nb_hip_shard_plan(data.total_len, data.mass_len, rank, nranks);
+    const char *ov = getenv("NB_HIP_OVERLAP");
+    if (ov) s->overlap = atoi(ov) ? 1 : 0;
+    ensure_device();  // the communicator binds to the current device
+    ncclUniqueId id;
+    memcpy(&id, unique_id128, NB_HIP_UNIQUE_ID_BYTES);
+    ASSERT_NCCL(rccl().CommInitRank(&s->comm, nranks, id, rank), "ncclCommInitRank(rank %d of %d)", rank, nranks);
+    return s;
+}
+
+void DestroySimPipeline(SimPipeline *sim) {
+    if (sim == nullptr) return;
+    release_device(sim);
+    if (sim->comm) ASSERT_NCCL(rccl().CommDestroy(sim->comm), "ncclCommDestroy");
+    delete sim;
+}
+
+void SetSimulationData(SimPipeline *s, const Particle *ps) {
+    NB_ASSERT(s != nullptr, "NULL pipeline");
+    NB_ASSERT(ps != nullptr || s->data.total_len == 0, "NULL particle array");
+    materialize(s);
+    const uint32_t N = s->data.total_len, M = s->data.mass_len;
+    if (N == 0) return;
+    hipStream_t st = s->stream;
+    ASSERT_HIP(hipMemcpyAsync(s->aos, ps, (size_t)N * sizeof(Particle), hipMemcpyHostToDevice, st), "H2D of %u particles", N);
+    s->cur = 0;
+    if (s->nranks == 1) {
+        nb::launch_split(st, s->aos, 0, N, s->pos[0], s->vel, s->acc, s->radius, s->mass, 0);
+        nb::launch_make_gm(st, s->mass, s->src_gm, M);
+    } else {
+        const NbShardPlan &pl = s->plan;
+        // receivers: [0, Mc) this rank's massive slice (tail padded), [Mc, Mc+Zc) its massless slice
+        nb::launch_fill_pad(st, s->pos[0], s->vel, s->acc, s->radius, s->mass, 0, s->slots);
+        nb::launch_split(st, s->aos, pl.mass_begin, pl.mass_count, s->pos[0], s->vel, s->acc, s->radius, s->mass, 0);
+        nb::launch_split(st, s->aos, pl.zero_begin, pl.zero_count, s->pos[0], s->vel, s->acc, s->radius, s->mass,
+                         pl.mass_chunk);
+        // sources: every rank holds the whole world in `aos`, so the first gathered array and the static
+        // G*m need no communication: rank q's slice is aos[q*Mc ..) padded
+        float2 *scratch_vel = dev_alloc<float2>(s->n_src);
+        float2 *scratch_acc = dev_alloc<float2>(s->n_src);
+        float *scratch_rad = dev_alloc<float>(s->n_src);
+        float *scratch_mass = dev_alloc<float>(s->n_src);
+        nb::launch_fill_pad(st, s->src_pos[0], scratch_vel, scratch_acc, scratch_rad, scratch_mass, 0, s->n_src);
+        nb::launch_split(st, s->aos, 0, M, s->src_pos[0], scratch_vel, scratch_acc, scratch_rad, scratch_mass, 0);
+        nb::launch_make_gm(st, scratch_mass, s->src_gm, s->n_src);
+        nb::launch_copy_f2(st, s->src_pos[1], s->src_pos[0], s->n_src);
+        ASSERT_HIP(hipStreamSynchronize(st), "sync after source setup");
+        dev_free(scratch_vel);
+        dev_free(scratch_acc);
+        dev_free(scratch_rad);
+        dev_free(scratch_mass);
+        if (s->overlap) ASSERT_HIP(hipEventRecord(s->ev_gather, s->comm_stream), "prime gather event");
+    }
+    ASSERT_HIP(hipStreamSynchronize(st), "sync after SetSimulationData");
+}
+
+void GetSimulationData(const SimPipeline *cs, Particle *ps) {
+    SimPipeline *s = const_cast<SimPipeline *>(cs);
+    NB_ASSERT(s != nullptr && ps != nullptr, "NULL argument");
+    NB_ASSERT(s->on_device, "GetSimulationData before SetSimulationData");
+    const uint32_t N = s->data.total_len;
+    if (N == 0) return;
+    hipStream_t st = s->stream;
+    if (s->nranks == 1) {
+        nb::launch_merge(st, s->aos, 0, N, s->pos[s->cur], s->vel, s->acc, s->radius, s->mass, 0);
+    } else {
+        // every rank merges its slots, the slices are all-gathered (uniform size), then unpacked into
+        // partitioned order: massive slices first, massless slices after them
+        const NbShardPlan &pl = s->plan;
+        Particle *shard = static_cast<Particle *>(s->aos_shard);
+        Particle *mine = shard + (size_t)s->rank * s->slots;
+        nb::launch_merge(st, mine, 0, s->slots, s->pos[s->cur], s->vel, s->acc, s->radius, s->mass, 0);
+        const size_t floats = (size_t)s->slots * (sizeof(Particle) / sizeof(float));
+        ASSERT_NCCL(rccl().AllGather(mine, shard, floats, NCCL_FLOAT32, s->comm, st), "ncclAllGather of particle slices");
+        for (int q = 0; q < s->nranks; q++) {
+            const NbShardPlan pq = nb_hip_shard_plan(N, s->data.mass_len, q, s->nranks);
+            const Particle *from = shard + (size_t)q * s->slots;
+            if (pq.mass_count)
+                ASSERT_HIP(hipMemcpyAsync(static_cast<Particle *>(s->aos) + pq.mass_begin, from,
+                                          (size_t)pq.mass_count * sizeof(Particle), hipMemcpyDeviceToDevice, st),
+                           "unpack massive slice of rank %d", q);
+            if (pq.zero_count)
+                ASSERT_HIP(hipMemcpyAsync(static_cast<Particle *>(s->aos) + pq.zero_begin, from + pl.mass_chunk,
+                                          (size_t)pq.zero_count * sizeof(Particle), hipMemcpyDeviceToDevice, st),
+                           "unpack massless slice of rank %d", q);
+        }
+    }
+    ASSERT_HIP(hipMemcpyAsync(ps, s->aos, (size_t)N * sizeof(Particle), hipMemcpyDeviceToHost, st), "D2H of %u particles", N);
+    ASSERT_HIP(hipStreamSynchronize(st), "sync after GetSimulationData");
+}
+
+void nb_hip_step_async(SimPipeline *s, uint32_t n, float dt) {
+    NB_ASSERT(s != nullptr, "NULL pipeline");
+    enqueue_steps(s, n, dt);
+}
+
+void nb_hip_sync(SimPipeline *s) {
+    NB_ASSERT(s != nullptr, "NULL pipeline");
+    if (!s->on_device) return;
+    ASSERT_HIP(hipStreamSynchronize(s->stream), "stream sync");
+    if (s->comm_stream) ASSERT_HIP(hipStreamSynchronize(s->comm_stream), "comm stream sync");
+}
+
+void PerformSimUpdate(SimPipeline *s, uint32_t n, float dt) {
+    nb_hip_step_async(s, n, dt);
+    nb_hip_sync(s);
+}
+
+double nb_hip_last_step_ms(SimPipeline *s, uint32_t *launches) {
+    NB_ASSERT(s != nullptr, "NULL pipeline");
+    if (launches) *launches = 0;
+    if (!s->on_device || !s->timed) return 0.0;
+    ASSERT_HIP(hipEventSynchronize(s->ev_end), "event sync");
+    float ms = 0.0f;
+    ASSERT_HIP(hipEventElapsedTime(&ms, s->ev_begin, s->ev_end), "hipEventElapsedTime");
+    if (launches) *launches = s->timed_launches;
+    return (double)ms;
+}
+
+int nb_hip_configure(SimPipeline *s, const char *key, int value) {
+    NB_ASSERT(s != nullptr && key != nullptr, "NULL argument");
+    int old = 0;
+    if (!strcmp(key, "variant")) {
+        NB_ASSERT(value == 0 || value == 1, "variant must be 0 (lds) or 1 (smem), got %d", value);
+        old = s->want_variant;
+        s->want_variant = value;
+    } else if (!strcmp(key, "k")) {
+        NB_ASSERT(value == 0 || value == 1 || value == 2 || value == 4, "k must be 0, 1, 2 or 4, got %d", value);
+        old = s->want_k;
+        s->want_k = value;
+    } else if (!strcmp(key, "w")) {
+        NB_ASSERT(value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16,
+                  "w must be 0, 1, 2, 4, 8 or 16, got %d", value);
+        old = s->want_w;
+        s->want_w = value;
+    } else if (!strcmp(key, "graph")) {
+        old = s->use_graph;
+        s->use_graph = value ? 1 : 0;
+    } else if (!strcmp(key, "overlap")) {
+        old = s->overlap;
+        if (s->on_device && s->nranks > 1) nb_hip_sync(s);
+        s->overlap = value ? 1 : 0;
+        if (s->on_device && s->overlap && s->nranks > 1)
+            ASSERT_HIP(hipEventRecord(s->ev_gather, s->comm_stream), "prime gather event");
+    } else {
+        NB_FAIL("unknown knob \"%s\"", key);
+    }
+    return old;
+}
+
+void nb_hip_launch_shape(const SimPipeline *s, int *k, int *w, int *variant, uint32_t *workgroups) {
+    NB_ASSERT(s != nullptr, "NULL pipeline");
+    if (k) *k = s->last_shape.k;
+    if (w) *w = s->last_shape.w;
+    if (variant) *variant = s->last_shape.variant;
+    if (workgroups) *workgroups = s->last_groups;
+}
+
+}  // extern "C"
