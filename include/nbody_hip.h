@@ -144,6 +144,17 @@ typedef struct NbShardPlan {
 
 NbShardPlan nb_hip_shard_plan(uint32_t total_len, uint32_t mass_len, int rank, int nranks);
 
+/*
+ * Local transport (testing aid): all nranks shards live in THIS process on the current device and
+ * exchange sources by device copies instead of RCCL.  Same shard plan, same kernels, same mirror /
+ * gather layout as the RCCL path, so a single-GPU box can verify the sharded arithmetic end to end.
+ * out[] receives nranks pipelines; feed each the same full array with SetSimulationData, advance them
+ * together with nb_hip_local_group_step (PerformSimUpdate on a member aborts), read any member with
+ * GetSimulationData, destroy every member with DestroySimPipeline.
+ */
+int nb_hip_local_group_create(WorldData data, int nranks, SimPipeline **out);
+void nb_hip_local_group_step(SimPipeline **sims, int nranks, uint32_t n, float dt);
+
 /* Library/ABI version: major*10000 + minor*100 + patch. */
 int nb_hip_version(void);
 

@@ -53,6 +53,8 @@ HIP_API = {
     "nb_hip_comm_unique_id": (None, [C.c_void_p]),
     "CreateSimPipelineSharded": (C.c_void_p, [WorldData, C.c_int, C.c_int, C.c_void_p]),
     "nb_hip_shard_plan": (NbShardPlan, [C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
+    "nb_hip_local_group_create": (C.c_int, [WorldData, C.c_int, C.POINTER(C.c_void_p)]),
+    "nb_hip_local_group_step": (None, [C.POINTER(C.c_void_p), C.c_int, C.c_uint32, C.c_float]),
     "nb_hip_version": (C.c_int, []),
 }
 
@@ -189,6 +191,38 @@ class SimPipeline:
         k, w, v, g = C.c_int(), C.c_int(), C.c_int(), C.c_uint32()
         hip_lib().nb_hip_launch_shape(self._h, C.byref(k), C.byref(w), C.byref(v), C.byref(g))
         return {"k": k.value, "w": w.value, "variant": "smem" if v.value else "lds", "workgroups": g.value}
+
+
+class LocalShardGroup:
+    """nranks shards of one world inside this process (include/nbody_hip.h "Local transport")."""
+
+    def __init__(self, total_len, mass_len, nranks, **knobs):
+        L = hip_lib()
+        self.nranks = nranks
+        self._arr = (C.c_void_p * nranks)()
+        L.nb_hip_local_group_create(WorldData(total_len, mass_len, 0.0), nranks, self._arr)
+        self.members = []
+        for r in range(nranks):
+            m = SimPipeline.__new__(SimPipeline)
+            m._h = self._arr[r]
+            m.total_len, m.mass_len, m.rank, m.nranks = total_len, mass_len, r, nranks
+            m.configure(**knobs)
+            self.members.append(m)
+
+    def set_data(self, particles):
+        for m in self.members:
+            m.set_data(particles)
+
+    def step(self, n, dt):
+        hip_lib().nb_hip_local_group_step(self._arr, self.nranks, n, dt)
+
+    def get_data(self, rank=0):
+        return self.members[rank].get_data()
+
+    def close(self):
+        for m in self.members:
+            m.close()
+        self.members = []
 
 
 class World:

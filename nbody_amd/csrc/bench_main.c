@@ -1,0 +1,128 @@
+/*
+ * bench_main.c -- nbody-bench for the MI355X build.
+ *
+ * With no size flags it reproduces the reference harness (src/bench.c:21-74):
+ * srand(11037) once, then for each N of its table MakeGalaxies(N, 2), one World
+ * per backend, 10 warm-up steps and 100 timed steps at dt = 1 in a single
+ * UpdateWorld_* call, microseconds per step printed per backend.  `--cpu` /
+ * `--gpu` restrict the backends exactly as there (bench.c:44-48).
+ *
+ * Extras the BASELINE.json configurations need:
+ *   --n N          one size instead of the table (repeatable)
+ *   --steps K      timed steps            (default 100)
+ *   --warmup W     untimed steps          (default 10)
+ *   --dt DT        step size              (default 1.0, the reference's)
+ *   --galaxies G   galaxies per universe  (default 2)
+ *   --seed S       srand seed             (default 11037)
+ * and two more columns: interactions/s = N * mass_len * steps / time.
+ */
+#include <stdbool.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <galaxy.h>
+#include <nbody.h>
+
+typedef void (*UpdateFn)(World *, float, uint32_t);
+
+static double seconds_now(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* one warm-up call, one timed call; returns seconds per step */
+static double time_backend(World *w, UpdateFn update, float dt, uint32_t warmup, uint32_t steps) {
+    update(w, dt, warmup);
+    const double t0 = seconds_now();
+    update(w, dt, steps);
+    const double t1 = seconds_now();
+    return (t1 - t0) / (double)steps;
+}
+
+static uint32_t count_massive(const Particle *ps, uint32_t n) {
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < n; i++) m += ps[i].mass > 0;
+    return m;
+}
+
+static const uint32_t REFERENCE_SIZES[] = {250, 500, 800, 1200, 2000, 4000, 10000, 20000, 50000, 100000};
+
+int main(int argc, char **argv) {
+    bool use_cpu = true, use_gpu = true;
+    uint32_t sizes[64];
+    uint32_t n_sizes = 0;
+    uint32_t steps = 100, warmup = 10, galaxies = 2;
+    unsigned seed = 11037;
+    float dt = 1.f;
+
+    for (int a = 1; a < argc; a++) {
+        const char *arg = argv[a];
+        const char *val = a + 1 < argc ? argv[a + 1] : NULL;
+        if (!strcmp(arg, "--cpu")) {
+            use_gpu = false;
+        } else if (!strcmp(arg, "--gpu")) {
+            use_cpu = false;
+        } else if (!strcmp(arg, "--n") && val && n_sizes < 64) {
+            sizes[n_sizes++] = (uint32_t)strtoul(val, NULL, 0), a++;
+        } else if (!strcmp(arg, "--steps") && val) {
+            steps = (uint32_t)strtoul(val, NULL, 0), a++;
+        } else if (!strcmp(arg, "--warmup") && val) {
+            warmup = (uint32_t)strtoul(val, NULL, 0), a++;
+        } else if (!strcmp(arg, "--dt") && val) {
+            dt = strtof(val, NULL), a++;
+        } else if (!strcmp(arg, "--galaxies") && val) {
+            galaxies = (uint32_t)strtoul(val, NULL, 0), a++;
+        } else if (!strcmp(arg, "--seed") && val) {
+            seed = (unsigned)strtoul(val, NULL, 0), a++;
+        } else {
+            fprintf(stderr,
+                    "usage: %s [--cpu|--gpu] [--n N]... [--steps K] [--warmup W] [--dt DT] [--galaxies G] [--seed S]\n",
+                    argv[0]);
+            return 2;
+        }
+    }
+    if (n_sizes == 0) {
+        n_sizes = sizeof REFERENCE_SIZES / sizeof REFERENCE_SIZES[0];
+        memcpy(sizes, REFERENCE_SIZES, sizeof REFERENCE_SIZES);
+    }
+    if (steps == 0) steps = 1;
+
+    srand(seed); /* one seed for the whole table, as the reference */
+
+    printf("\t      N");
+    if (use_cpu) printf("\t    CPU");
+    if (use_gpu) printf("\t    GPU");
+    if (use_cpu) printf("\t  CPU int/s");
+    if (use_gpu) printf("\t  GPU int/s");
+    printf("\n");
+
+    for (uint32_t s = 0; s < n_sizes; s++) {
+        const uint32_t n = sizes[s];
+        Particle *ps = MakeGalaxies(n, galaxies);
+        const double pairs = (double)n * (double)count_massive(ps, n);
+
+        double cpu_s = 0, gpu_s = 0;
+        if (use_cpu) {
+            World *w = CreateWorld(ps, n);
+            cpu_s = time_backend(w, UpdateWorld_CPU, dt, warmup, steps);
+            DestroyWorld(w);
+        }
+        if (use_gpu) {
+            World *w = CreateWorld(ps, n);
+            gpu_s = time_backend(w, UpdateWorld_GPU, dt, warmup, steps);
+            DestroyWorld(w);
+        }
+        printf("\t%7u", n);
+        if (use_cpu) printf("\t%7ld", (long)(cpu_s * 1e6));
+        if (use_gpu) printf("\t%7ld", (long)(gpu_s * 1e6));
+        if (use_cpu) printf("\t%11.3e", pairs / cpu_s);
+        if (use_gpu) printf("\t%11.3e", pairs / gpu_s);
+        printf("\n");
+        fflush(stdout);
+        free(ps);
+    }
+    return 0;
+}

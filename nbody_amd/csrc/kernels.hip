@@ -35,7 +35,21 @@ typedef float v8f __attribute__((ext_vector_type(8)));
 template <int K>
 struct Receivers {
     float x[K], y[K], r[K];
-    float ax[K], ay[K];
+    float ax[K], ay[K];  // running sums of the current 64-source chunk
+    float sx[K], sy[K];  // sums of the finished chunks (two-level summation keeps fp32 sums of 10^5..10^6
+                         // terms about as accurate as the reference's 8-lane AVX sums, for 2 adds per chunk)
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int k = 0; k < K; k++) ax[k] = ay[k] = sx[k] = sy[k] = 0.0f;
+    }
+    __device__ __forceinline__ void close_chunk() {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            sx[k] += ax[k];
+            sy[k] += ay[k];
+            ax[k] = ay[k] = 0.0f;
+        }
+    }
 };
 
 // One source against the K receivers of this lane.  sx/sy/sg are wave-uniform.
@@ -81,9 +95,8 @@ __global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
         R.x[k] = q.x;
         R.y[k] = q.y;
         R.r[k] = p.radius[i];
-        R.ax[k] = 0.0f;
-        R.ay[k] = 0.0f;
     }
+    R.clear();
 
     // this wave's slice of the concatenated source ranges, in whole chunks
     const uint32_t n0 = p.src_end[0] - p.src_begin[0];
@@ -126,6 +139,7 @@ __global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
                 interact<K>(R, X.z, Y.z, G.z);
                 interact<K>(R, X.w, Y.w, G.w);
             }
+            R.close_chunk();
             buf ^= 1;
         }
     } else {
@@ -145,6 +159,8 @@ __global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
             // multiples of 64 sources from 64-aligned range starts, so j is a multiple of 8 here.
             const float *__restrict__ sp = reinterpret_cast<const float *>(p.src_pos);
             const float *__restrict__ sg = p.src_gm;
+            // every 8 groups (64 sources) the chunk sums are closed, exactly where the LDS variant's tiles end,
+            // so both variants add in the same order; a short last chunk may end in single sources
             const uint32_t groups = (j_end - j) / 8;
             if (groups > 0) {
                 v16f P = *reinterpret_cast<const v16f *>(sp + 2 * (size_t)j);
@@ -159,9 +175,11 @@ __global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
                     }
 #pragma unroll
                     for (int u = 0; u < 8; u++) interact<K>(R, Pc[2 * u], Pc[2 * u + 1], Gc[u]);
+                    if ((g & 7u) == 7u) R.close_chunk();
                 }
             }
             for (; j < j_end; j++) interact<K>(R, sp[2 * (size_t)j], sp[2 * (size_t)j + 1], sg[j]);
+            R.close_chunk();  // the short last chunk (adds exact zeros when there is none)
         }
     }
 
@@ -190,10 +208,10 @@ __global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
 
     if constexpr (W == 1) {
 #pragma unroll
-        for (int k = 0; k < K; k++) finish(recv_base + k * WAVE + lane, R.ax[k], R.ay[k]);
+        for (int k = 0; k < K; k++) finish(recv_base + k * WAVE + lane, R.sx[k], R.sy[k]);
     } else {
 #pragma unroll
-        for (int k = 0; k < K; k++) partial[wid][k * WAVE + lane] = make_float2(R.ax[k], R.ay[k]);
+        for (int k = 0; k < K; k++) partial[wid][k * WAVE + lane] = make_float2(R.sx[k], R.sy[k]);
         __syncthreads();
 #pragma unroll
         for (uint32_t slot = tid; slot < WAVE * K; slot += WAVE * W) {
@@ -281,23 +299,19 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, int compute_units) {
     LaunchShape s = want;
     if (compute_units <= 0) compute_units = 256;
     if (s.k == 0) {
-        // deepest register blocking that still leaves two workgroups per CU
+        // deepest register blocking that still gives every CU a workgroup (measured: profiles/r01_probe1)
         s.k = 1;
         for (int k = 4; k >= 1; k /= 2) {
             const uint32_t groups = (n_recv + WAVE * k - 1) / (WAVE * k);
-            if (groups >= 2u * (uint32_t)compute_units) {
+            if (groups >= (uint32_t)compute_units) {
                 s.k = k;
                 break;
             }
         }
     }
     if (s.w == 0) {
-        // enough source slices that the chip holds ~8 waves per SIMD
-        const uint32_t groups = (n_recv + WAVE * s.k - 1) / (WAVE * s.k);
-        const uint32_t want_waves = 8u * 4u * (uint32_t)compute_units;
-        int w = 1;
-        while (w < 16 && groups * (uint32_t)w < want_waves) w *= 2;
-        s.w = w;
+        // 16 source slices per workgroup: fastest at every size measured, and the shortest fp32 sums
+        s.w = 16;
     }
     return s;
 }

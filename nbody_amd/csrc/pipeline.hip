@@ -162,12 +162,19 @@ struct StepGraph {
 
 }  // namespace
 
+struct LocalGroup {
+    std::vector<SimPipeline *> members;
+    hipStream_t stream = nullptr;  // every member enqueues here, so program order is the only ordering needed
+};
+
 struct SimPipeline {
     WorldData data;
     // sharding (nranks == 1: the whole world on one device)
     int rank = 0, nranks = 1;
+    bool sharded = false;  // RCCL path (nranks > 1, or forced for single-GPU testing of that path)
     NbShardPlan plan;
     ncclComm_t comm = nullptr;
+    struct LocalGroup *group = nullptr;  // test transport: all ranks are pipelines of this process (no RCCL)
 
     bool on_device = false;  // buffers exist and hold data
     uint32_t slots = 0;      // receiver slots on this device
@@ -201,6 +208,8 @@ struct SimPipeline {
     std::vector<StepGraph> graphs;
 };
 
+struct SimPipeline;
+
 namespace {
 
 constexpr uint32_t GRAPH_CHAIN_MAX = 64;  // longer requests replay an even-length chain
@@ -221,7 +230,7 @@ void release_device(SimPipeline *s) {
     s->graphs.clear();
     for (int b = 0; b < 2; b++) {
         dev_free(s->pos[b]);
-        if (s->nranks > 1) dev_free(s->src_pos[b]);
+        if (s->sharded) dev_free(s->src_pos[b]);
         s->pos[b] = s->src_pos[b] = nullptr;
     }
     dev_free(s->vel);
@@ -236,7 +245,7 @@ void release_device(SimPipeline *s) {
     ASSERT_HIP(hipEventDestroy(s->ev_local), "event");
     ASSERT_HIP(hipEventDestroy(s->ev_gather), "event");
     if (s->comm_stream) ASSERT_HIP(hipStreamDestroy(s->comm_stream), "stream");
-    ASSERT_HIP(hipStreamDestroy(s->stream), "stream");
+    if (!s->group) ASSERT_HIP(hipStreamDestroy(s->stream), "stream");
     s->on_device = false;
 }
 
@@ -244,18 +253,21 @@ void release_device(SimPipeline *s) {
 void materialize(SimPipeline *s) {
     if (s->on_device) return;
     ensure_device();
-    ASSERT_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "stream");
+    if (s->group)
+        s->stream = s->group->stream;
+    else
+        ASSERT_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "stream");
     ASSERT_HIP(hipEventCreate(&s->ev_begin), "event");
     ASSERT_HIP(hipEventCreate(&s->ev_end), "event");
     ASSERT_HIP(hipEventCreateWithFlags(&s->ev_local, hipEventDisableTiming), "event");
     ASSERT_HIP(hipEventCreateWithFlags(&s->ev_gather, hipEventDisableTiming), "event");
 
     const uint32_t N = s->data.total_len, M = s->data.mass_len;
-    if (s->nranks == 1) {
+    if (!s->sharded) {
         s->slots = N;
         s->n_src = M;
     } else {
-        ASSERT_HIP(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking), "comm stream");
+        if (!s->group) ASSERT_HIP(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking), "comm stream");
         s->slots = s->plan.mass_chunk + s->plan.zero_chunk;
         s->n_src = s->plan.src_padded;
     }
@@ -267,7 +279,7 @@ void materialize(SimPipeline *s) {
     s->mass = dev_alloc<float>(cap);
     s->src_gm = dev_alloc<float>(s->n_src);
     s->aos = dev_alloc<Particle>(N);
-    if (s->nranks == 1) {
+    if (!s->sharded) {
         // the first mass_len receivers ARE the sources: no separate source array
         s->src_pos[0] = s->pos[0];
         s->src_pos[1] = s->pos[1];
@@ -302,7 +314,7 @@ nb::StepParams whole_step(const SimPipeline *s, int in, float dt) {
     p.acc = s->acc;
     p.radius = s->radius;
     p.n_recv = s->slots;
-    if (s->nranks > 1) {
+    if (s->sharded) {
         p.mirror = s->src_pos[in ^ 1] + (size_t)s->rank * s->plan.mass_chunk;
         p.n_mirror = s->plan.mass_chunk;
     }
@@ -398,45 +410,61 @@ void enqueue_single(SimPipeline *s, uint32_t n, float dt) {
 void allgather_sources(SimPipeline *s, int buf, hipStream_t st) {
     // in place: this rank's slice already sits at rank * Mc (written by the step kernel's mirror store)
     const size_t per_rank = (size_t)s->plan.mass_chunk * 2;  // floats
+    if (per_rank == 0) return;
     float *base = reinterpret_cast<float *>(s->src_pos[buf]);
+    if (s->group) {
+        // local transport: push the slice into every peer's gathered array (same device, same stream)
+        for (SimPipeline *peer : s->group->members) {
+            if (peer == s) continue;
+            float *dst = reinterpret_cast<float *>(peer->src_pos[buf]);
+            ASSERT_HIP(hipMemcpyAsync(dst + (size_t)s->rank * per_rank, base + (size_t)s->rank * per_rank,
+                                      per_rank * sizeof(float), hipMemcpyDeviceToDevice, st),
+                       "local push of rank %d's sources", s->rank);
+        }
+        return;
+    }
     ASSERT_NCCL(rccl().AllGather(base + (size_t)s->rank * per_rank, base, per_rank, NCCL_FLOAT32, s->comm, st),
                 "ncclAllGather of %zu floats per rank", per_rank);
 }
 
-void enqueue_sharded(SimPipeline *s, uint32_t n, float dt) {
-    const nb::LaunchShape sh = resolve_shape(s);
+// One sharded step of one rank.  `cs` carries the gather (the comm stream with RCCL; the group stream locally).
+void sharded_step(SimPipeline *s, nb::LaunchShape sh, float dt, hipStream_t cs) {
     const uint32_t Mc = s->plan.mass_chunk;
     const uint32_t own_lo = (uint32_t)s->rank * Mc, own_hi = own_lo + Mc;
-    for (uint32_t i = 0; i < n; i++) {
-        const int in = s->cur;
-        if (!s->overlap) {
-            // gather(positions of step t) -> one kernel over all sources
-            launch_step(s, sh, whole_step(s, in, dt), s->stream);
-            allgather_sources(s, in ^ 1, s->stream);
-        } else {
-            // own-shard sources are already here: start on them while the other P-1 slices of
-            // src_pos[in] are still arriving on the comm stream, then finish with the remote ones
-            nb::StepParams a = whole_step(s, in, dt);
-            a.src_begin[0] = own_lo;
-            a.src_end[0] = own_hi;
-            a.flags = nb::STEP_NO_FINALIZE;
-            a.n_mirror = 0;
-            launch_step(s, sh, a, s->stream);
-            ASSERT_HIP(hipStreamWaitEvent(s->stream, s->ev_gather, 0), "wait gather");
-            nb::StepParams b = whole_step(s, in, dt);
-            b.src_begin[0] = 0;
-            b.src_end[0] = own_lo;
-            b.src_begin[1] = own_hi;
-            b.src_end[1] = s->n_src;
-            b.flags = nb::STEP_ACC_IN;
-            launch_step(s, sh, b, s->stream);
-            ASSERT_HIP(hipEventRecord(s->ev_local, s->stream), "record local");
-            ASSERT_HIP(hipStreamWaitEvent(s->comm_stream, s->ev_local, 0), "comm waits for the new slice");
-            allgather_sources(s, in ^ 1, s->comm_stream);
-            ASSERT_HIP(hipEventRecord(s->ev_gather, s->comm_stream), "record gather");
-        }
-        s->cur ^= 1;
+    const int in = s->cur;
+    if (!s->overlap) {
+        // one kernel over all gathered sources, then gather the positions it produced
+        launch_step(s, sh, whole_step(s, in, dt), s->stream);
+        allgather_sources(s, in ^ 1, s->stream);
+    } else {
+        // own-shard sources are already here: start on them while the other P-1 slices of
+        // src_pos[in] are still arriving on the comm stream, then finish with the remote ones
+        nb::StepParams a = whole_step(s, in, dt);
+        a.src_begin[0] = own_lo;
+        a.src_end[0] = own_hi;
+        a.flags = nb::STEP_NO_FINALIZE;
+        a.n_mirror = 0;
+        launch_step(s, sh, a, s->stream);
+        ASSERT_HIP(hipStreamWaitEvent(s->stream, s->ev_gather, 0), "wait gather");
+        nb::StepParams b = whole_step(s, in, dt);
+        b.src_begin[0] = 0;
+        b.src_end[0] = own_lo;
+        b.src_begin[1] = own_hi;
+        b.src_end[1] = s->n_src;
+        b.flags = nb::STEP_ACC_IN;
+        launch_step(s, sh, b, s->stream);
+        ASSERT_HIP(hipEventRecord(s->ev_local, s->stream), "record local");
+        ASSERT_HIP(hipStreamWaitEvent(cs, s->ev_local, 0), "comm waits for the new slice");
+        allgather_sources(s, in ^ 1, cs);
+        ASSERT_HIP(hipEventRecord(s->ev_gather, cs), "record gather");
     }
+    s->cur ^= 1;
+}
+
+void enqueue_sharded(SimPipeline *s, uint32_t n, float dt) {
+    NB_ASSERT(s->group == nullptr, "members of a local group step through nb_hip_local_group_step");
+    const nb::LaunchShape sh = resolve_shape(s);
+    for (uint32_t i = 0; i < n; i++) sharded_step(s, sh, dt, s->comm_stream);
     if (s->overlap) ASSERT_HIP(hipStreamWaitEvent(s->stream, s->ev_gather, 0), "join comm stream");
 }
 
@@ -444,13 +472,13 @@ void enqueue_steps(SimPipeline *s, uint32_t n, float dt) {
     NB_ASSERT(s->on_device, "PerformSimUpdate before SetSimulationData");
     if (s->slots == 0 || n == 0) return;
     ASSERT_HIP(hipEventRecord(s->ev_begin, s->stream), "record begin");
-    if (s->nranks == 1)
+    if (!s->sharded)
         enqueue_single(s, n, dt);
     else
         enqueue_sharded(s, n, dt);
     ASSERT_HIP(hipEventRecord(s->ev_end, s->stream), "record end");
     s->timed = true;
-    s->timed_launches = (s->nranks > 1 && s->overlap) ? 2 * n : n;
+    s->timed_launches = (s->sharded && s->overlap) ? 2 * n : n;
     s->data.dt = dt;
 }
 
@@ -527,11 +555,15 @@ void nb_hip_comm_unique_id(void *out128) {
 
 SimPipeline *CreateSimPipelineSharded(WorldData data, int rank, int nranks, const void *unique_id128) {
     NB_ASSERT(nranks >= 1 && rank >= 0 && rank < nranks, "rank %d of %d", rank, nranks);
-    if (nranks == 1) return CreateSimPipeline(data);
+    // one rank normally means the plain pipeline; NB_HIP_FORCE_SHARDED=1 keeps the RCCL path (used to
+    // exercise it on a single-GPU box)
+    const char *force = getenv("NB_HIP_FORCE_SHARDED");
+    if (nranks == 1 && !(force && atoi(force))) return CreateSimPipeline(data);
     NB_ASSERT(unique_id128 != nullptr, "sharded pipeline needs the RCCL unique id");
     SimPipeline *s = CreateSimPipeline(data);
     s->rank = rank;
     s->nranks = nranks;
+    s->sharded = true;
     s->plan = nb_hip_shard_plan(data.total_len, data.mass_len, rank, nranks);
     const char *ov = getenv("NB_HIP_OVERLAP");
     if (ov) s->overlap = atoi(ov) ? 1 : 0;
@@ -542,9 +574,52 @@ SimPipeline *CreateSimPipelineSharded(WorldData data, int rank, int nranks, cons
     return s;
 }
 
+int nb_hip_local_group_create(WorldData data, int nranks, SimPipeline **out) {
+    NB_ASSERT(nranks >= 1 && out != nullptr, "bad local group request");
+    ensure_device();
+    LocalGroup *g = new LocalGroup();
+    ASSERT_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking), "group stream");
+    for (int r = 0; r < nranks; r++) {
+        SimPipeline *s = CreateSimPipeline(data);
+        s->rank = r;
+        s->nranks = nranks;
+        s->sharded = true;
+        s->group = g;
+        s->plan = nb_hip_shard_plan(data.total_len, data.mass_len, r, nranks);
+        g->members.push_back(s);
+        out[r] = s;
+    }
+    return nranks;
+}
+
+void nb_hip_local_group_step(SimPipeline **sims, int nranks, uint32_t n, float dt) {
+    NB_ASSERT(sims != nullptr && nranks >= 1 && sims[0]->group != nullptr, "not a local group");
+    LocalGroup *g = sims[0]->group;
+    NB_ASSERT((int)g->members.size() == nranks, "group has %zu members, %d passed", g->members.size(), nranks);
+    for (int r = 0; r < nranks; r++) NB_ASSERT(sims[r]->on_device, "member %d has no data", r);
+    for (uint32_t i = 0; i < n; i++)
+        for (int r = 0; r < nranks; r++) {
+            SimPipeline *s = sims[r];
+            if (s->slots == 0) continue;
+            sharded_step(s, resolve_shape(s), dt, g->stream);
+        }
+    ASSERT_HIP(hipStreamSynchronize(g->stream), "group sync");
+}
+
 void DestroySimPipeline(SimPipeline *sim) {
     if (sim == nullptr) return;
     release_device(sim);
+    if (sim->group) {
+        LocalGroup *g = sim->group;
+        for (auto &m : g->members)
+            if (m == sim) m = nullptr;
+        bool empty = true;
+        for (auto m : g->members) empty = empty && m == nullptr;
+        if (empty) {
+            ASSERT_HIP(hipStreamDestroy(g->stream), "group stream");
+            delete g;
+        }
+    }
     if (sim->comm) ASSERT_NCCL(rccl().CommDestroy(sim->comm), "ncclCommDestroy");
     delete sim;
 }
@@ -558,7 +633,7 @@ void SetSimulationData(SimPipeline *s, const Particle *ps) {
     hipStream_t st = s->stream;
     ASSERT_HIP(hipMemcpyAsync(s->aos, ps, (size_t)N * sizeof(Particle), hipMemcpyHostToDevice, st), "H2D of %u particles", N);
     s->cur = 0;
-    if (s->nranks == 1) {
+    if (!s->sharded) {
         nb::launch_split(st, s->aos, 0, N, s->pos[0], s->vel, s->acc, s->radius, s->mass, 0);
         nb::launch_make_gm(st, s->mass, s->src_gm, M);
     } else {
@@ -583,7 +658,7 @@ void SetSimulationData(SimPipeline *s, const Particle *ps) {
         dev_free(scratch_acc);
         dev_free(scratch_rad);
         dev_free(scratch_mass);
-        if (s->overlap) ASSERT_HIP(hipEventRecord(s->ev_gather, s->comm_stream), "prime gather event");
+        if (s->overlap) ASSERT_HIP(hipEventRecord(s->ev_gather, s->group ? s->stream : s->comm_stream), "prime gather event");
     }
     ASSERT_HIP(hipStreamSynchronize(st), "sync after SetSimulationData");
 }
@@ -595,7 +670,7 @@ void GetSimulationData(const SimPipeline *cs, Particle *ps) {
     const uint32_t N = s->data.total_len;
     if (N == 0) return;
     hipStream_t st = s->stream;
-    if (s->nranks == 1) {
+    if (!s->sharded) {
         nb::launch_merge(st, s->aos, 0, N, s->pos[s->cur], s->vel, s->acc, s->radius, s->mass, 0);
     } else {
         // every rank merges its slots, the slices are all-gathered (uniform size), then unpacked into
@@ -603,9 +678,16 @@ void GetSimulationData(const SimPipeline *cs, Particle *ps) {
         const NbShardPlan &pl = s->plan;
         Particle *shard = static_cast<Particle *>(s->aos_shard);
         Particle *mine = shard + (size_t)s->rank * s->slots;
-        nb::launch_merge(st, mine, 0, s->slots, s->pos[s->cur], s->vel, s->acc, s->radius, s->mass, 0);
-        const size_t floats = (size_t)s->slots * (sizeof(Particle) / sizeof(float));
-        ASSERT_NCCL(rccl().AllGather(mine, shard, floats, NCCL_FLOAT32, s->comm, st), "ncclAllGather of particle slices");
+        if (s->group) {
+            for (SimPipeline *q : s->group->members)
+                nb::launch_merge(st, shard + (size_t)q->rank * s->slots, 0, q->slots, q->pos[q->cur], q->vel, q->acc,
+                                 q->radius, q->mass, 0);
+        } else {
+            nb::launch_merge(st, mine, 0, s->slots, s->pos[s->cur], s->vel, s->acc, s->radius, s->mass, 0);
+            const size_t floats = (size_t)s->slots * (sizeof(Particle) / sizeof(float));
+            ASSERT_NCCL(rccl().AllGather(mine, shard, floats, NCCL_FLOAT32, s->comm, st),
+                        "ncclAllGather of particle slices");
+        }
         for (int q = 0; q < s->nranks; q++) {
             const NbShardPlan pq = nb_hip_shard_plan(N, s->data.mass_len, q, s->nranks);
             const Particle *from = shard + (size_t)q * s->slots;
@@ -672,10 +754,10 @@ int nb_hip_configure(SimPipeline *s, const char *key, int value) {
         s->use_graph = value ? 1 : 0;
     } else if (!strcmp(key, "overlap")) {
         old = s->overlap;
-        if (s->on_device && s->nranks > 1) nb_hip_sync(s);
+        if (s->on_device && s->sharded) nb_hip_sync(s);
         s->overlap = value ? 1 : 0;
-        if (s->on_device && s->overlap && s->nranks > 1)
-            ASSERT_HIP(hipEventRecord(s->ev_gather, s->comm_stream), "prime gather event");
+        if (s->on_device && s->overlap && s->sharded)
+            ASSERT_HIP(hipEventRecord(s->ev_gather, s->group ? s->stream : s->comm_stream), "prime gather event");
     } else {
         NB_FAIL("unknown knob \"%s\"", key);
     }

@@ -1,0 +1,112 @@
+/*
+ * world.c -- the include/nbody.h surface: World, its mass partition, and the
+ * lazy host<->device coherence between the particle array and the HIP pipeline.
+ *
+ * Follows the behaviour of the reference's src/lib/world.c:
+ *   - CreateWorld copies the caller's particles and partitions them "mass > 0
+ *     first" with the reference's two-cursor swap scheme (world.c:32-46), because
+ *     that exact permutation is the index order every later read returns
+ *     (pinned by reference test/test_particle_sort.c:27-111);
+ *   - two dirty flags decide when data crosses PCIe (world.c:18-19,76-89): the
+ *     array is uploaded only if the CPU side changed it since the last GPU step,
+ *     and downloaded only when GetWorldParticles / UpdateWorld_CPU needs it;
+ *   - UpdateWorld_GPU(n == 0) does nothing (world.c:113); UpdateWorld_CPU(n == 0)
+ *     still pulls the device state and marks the array dirty (world.c:100,109).
+ * Differences: the GPU side is created lazily (no device is touched by a World
+ * that only ever steps on the CPU), and DestroyWorld frees the particle array
+ * (the reference leaks it, world.c:67-73).
+ */
+#include "nbody.h"
+#include "nbody_hip.h"
+
+#include <stdbool.h>
+
+#include "nb_util.h"
+#include "sim_cpu.h"
+
+struct World {
+    Particle *particles;  /* partitioned copy of the caller's array */
+    uint32_t count;       /* all particles */
+    uint32_t massive;     /* particles with mass > 0; they occupy [0, massive) */
+    SimPipeline *gpu;     /* HIP pipeline (include/nbody_hip.h) */
+    CpuSim *cpu;          /* host-core stepper */
+    bool host_is_newer;   /* array changed since the device last saw it */
+    bool device_is_newer; /* device stepped since the array was last refreshed */
+};
+
+/*
+ * In-place unstable partition, massive particles first; returns their count.
+ * `lo` hunts upward for a massless slot, `hi` downward for a massive one, and
+ * they swap until they meet -- the reference's scheme, kept because its output
+ * permutation is part of the observable contract.
+ */
+static uint32_t partition_by_mass(Particle *p, uint32_t count) {
+    uint32_t lo = 0, hi = count;
+    for (;;) {
+        for (; lo < hi && p[lo].mass > 0; lo++) {
+        }
+        while (lo < hi) {
+            hi--;
+            if (!(p[hi].mass <= 0)) break;
+        }
+        if (lo == hi) return hi;
+        const Particle keep = p[lo];
+        p[lo] = p[hi];
+        p[hi] = keep;
+    }
+}
+
+World *CreateWorld(const Particle *ps, uint32_t size) {
+    World *w = NB_NEW(1, World);
+    NB_CHECK(w != NULL, "Failed to alloc World");
+    w->particles = NB_NEW(size ? size : 1, Particle);
+    NB_CHECK(w->particles != NULL, "Failed to alloc %u particles", size);
+    if (size) memcpy(w->particles, ps, (size_t)size * sizeof(Particle));
+
+    w->count = size;
+    w->massive = partition_by_mass(w->particles, size);
+    w->gpu = CreateSimPipeline((WorldData){.total_len = size, .mass_len = w->massive, .dt = 0.0f});
+    w->cpu = CpuSimCreate(w->massive);
+    w->host_is_newer = true;    /* the device has seen nothing yet */
+    w->device_is_newer = false;
+    return w;
+}
+
+void DestroyWorld(World *w) {
+    if (w == NULL) return;
+    DestroySimPipeline(w->gpu);
+    CpuSimDestroy(w->cpu);
+    free(w->particles);
+    free(w);
+}
+
+static void push_if_stale(World *w) {
+    if (!w->host_is_newer) return;
+    SetSimulationData(w->gpu, w->particles);
+    w->host_is_newer = false;
+}
+
+static void pull_if_stale(World *w) {
+    if (!w->device_is_newer) return;
+    GetSimulationData(w->gpu, w->particles);
+    w->device_is_newer = false;
+}
+
+const Particle *GetWorldParticles(World *w, uint32_t *size) {
+    pull_if_stale(w);
+    if (size != NULL) *size = w->count;
+    return w->particles;
+}
+
+void UpdateWorld_CPU(World *w, float dt, uint32_t n) {
+    pull_if_stale(w);
+    for (uint32_t step = 0; step < n; step++) CpuSimStep(w->cpu, w->particles, w->count, w->massive, dt);
+    w->host_is_newer = true;
+}
+
+void UpdateWorld_GPU(World *w, float dt, uint32_t n) {
+    if (n == 0) return;
+    push_if_stale(w);
+    PerformSimUpdate(w->gpu, n, dt);
+    w->device_is_newer = true;
+}

@@ -299,6 +299,41 @@ void orc_acc_f64(const Particle *arr, uint32_t total_len, uint32_t mass_len,
     }
 }
 
+void orc_acc_f64_subset(const Particle *arr, uint32_t mass_len, const uint32_t *idx, uint32_t n_idx,
+                        double *acc_xy, double *abs_xy) {
+#pragma omp parallel for schedule(dynamic, 4)
+    for (uint32_t q = 0; q < n_idx; q++) {
+        const uint32_t i = idx[q];
+        const double x = arr[i].pos.x, y = arr[i].pos.y, r = arr[i].radius;
+        double ax = 0, ay = 0, bx = 0, by = 0;
+        for (uint32_t j = 0; j < mass_len; j++) {
+            double dx = (double)arr[j].pos.x - x;
+            double dy = (double)arr[j].pos.y - y;
+            double r2 = dx * dx + dy * dy + r;
+            double f = ((double)arr[j].mass * (double)NB_G) / (sqrt(r2) * r2);
+            ax += dx * f;
+            ay += dy * f;
+            bx += fabs(dx * f);
+            by += fabs(dy * f);
+        }
+        acc_xy[2 * q] = ax;
+        acc_xy[2 * q + 1] = ay;
+        abs_xy[2 * q] = bx;
+        abs_xy[2 * q + 1] = by;
+    }
+}
+
+void orc_acc_avx_subset(const Particle *arr, uint32_t mass_len, const uint32_t *idx, uint32_t n_idx, float *acc_xy) {
+    Snapshot s = snapshot_alloc(mass_len);
+    snapshot_fill(&s, arr, mass_len);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (uint32_t q = 0; q < n_idx; q++) {
+        const Particle *p = &arr[idx[q]];
+        force_avx(&s, p->pos.x, p->pos.y, p->radius, &acc_xy[2 * q], &acc_xy[2 * q + 1]);
+    }
+    snapshot_free(&s);
+}
+
 void orc_step_f64(Particle *arr, uint32_t total_len, uint32_t mass_len, float dt, uint32_t n) {
     if (n == 0) return;
     double *st = (double *)malloc((size_t)total_len * 4 * sizeof(double)); /* x y vx vy */

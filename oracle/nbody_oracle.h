@@ -65,6 +65,13 @@ void orc_step_seq(Particle *arr, uint32_t total_len, uint32_t mass_len, float dt
 void orc_acc_f64(const Particle *arr, uint32_t total_len, uint32_t mass_len,
                  double *acc_xy, double *abs_xy);
 
+/* the same for the receivers idx[0..n_idx) only: acc_xy/abs_xy have 2*n_idx entries (full-size spot checks) */
+void orc_acc_f64_subset(const Particle *arr, uint32_t mass_len, const uint32_t *idx, uint32_t n_idx,
+                        double *acc_xy, double *abs_xy);
+
+/* the reference-AVX-order fp32 accelerations (bit-exact with orc_step_avx) of the receivers idx only */
+void orc_acc_avx_subset(const Particle *arr, uint32_t mass_len, const uint32_t *idx, uint32_t n_idx, float *acc_xy);
+
 /* n steps integrated entirely in float64 state, written back rounded; trend checks only */
 void orc_step_f64(Particle *arr, uint32_t total_len, uint32_t mass_len, float dt, uint32_t n);
 

@@ -27,7 +27,8 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(ORACLE_SO):
+        src = os.path.join(ORACLE_DIR, "nbody_oracle.c")
+        if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
             build()
         L = C.CDLL(ORACLE_SO)
         L.orc_partition.restype = C.c_uint32
@@ -40,6 +41,10 @@ def lib():
             f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32]
         L.orc_acc_f64.restype = None
         L.orc_acc_f64.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_acc_f64_subset.restype = None
+        L.orc_acc_f64_subset.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_acc_avx_subset.restype = None
+        L.orc_acc_avx_subset.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_time_avx_sample.restype = C.c_double
         L.orc_time_avx_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float,
                                           C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
@@ -80,6 +85,25 @@ def acc_f64(a, mass_len):
     mag = np.zeros((n, 2), dtype=np.float64)
     lib().orc_acc_f64(a.ctypes.data, n, mass_len, acc.ctypes.data, mag.ctypes.data)
     return acc, mag
+
+
+def acc_f64_subset(a, mass_len, idx):
+    """float64 accelerations (and sum of |contributions|) of the receivers idx only."""
+    a = _check(np.ascontiguousarray(a, dtype=np.float32))
+    idx = np.ascontiguousarray(idx, dtype=np.uint32)
+    acc = np.zeros((idx.size, 2), dtype=np.float64)
+    mag = np.zeros((idx.size, 2), dtype=np.float64)
+    lib().orc_acc_f64_subset(a.ctypes.data, mass_len, idx.ctypes.data, idx.size, acc.ctypes.data, mag.ctypes.data)
+    return acc, mag
+
+
+def acc_avx_subset(a, mass_len, idx):
+    """fp32 accelerations the reference AVX path would produce for the receivers idx (bit-exact order)."""
+    a = _check(np.ascontiguousarray(a, dtype=np.float32))
+    idx = np.ascontiguousarray(idx, dtype=np.uint32)
+    acc = np.zeros((idx.size, 2), dtype=np.float32)
+    lib().orc_acc_avx_subset(a.ctypes.data, mass_len, idx.ctypes.data, idx.size, acc.ctypes.data)
+    return acc
 
 
 def time_avx_sample(a, mass_len, recv_begin, recv_end, dt=0.01, threads=0):

@@ -1,0 +1,117 @@
+"""The C-ABI boundary without a GPU: libraries load, export what include/*.h declares, host-only calls work."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import nbody_amd as nb
+
+ROOT = nb.ROOT
+FUNC = re.compile(r"^\s*(?:const\s+)?[A-Za-z_][\w\s\*]*?\b([A-Za-z_]\w*)\s*\([^;{]*\)\s*;", re.M)
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)          # comments
+    text = re.sub(r"static inline[^{]*\{[^}]*\}", "", text)     # inline helpers are not exports
+    names = [m.group(1) for m in FUNC.finditer(text)]
+    return [n for n in names if n not in ("defined", "static_assert", "_Static_assert")]
+
+
+def exported(so):
+    out = subprocess.run(["nm", "-D", "--defined-only", so], check=True, capture_output=True, text=True).stdout
+    return {line.split()[-1] for line in out.splitlines() if line.strip()}
+
+
+def test_hip_library_exports_every_declared_symbol():
+    names = declared_functions("nbody_hip.h")
+    assert {"CreateSimPipeline", "DestroySimPipeline", "GetSimulationData", "SetSimulationData",
+            "PerformSimUpdate"} <= set(names)      # the reference seam, src/lib/sim_gpu.h:21-36
+    have = exported(nb.HIP_SO)
+    missing = [n for n in names if n not in have]
+    assert not missing, f"libnbody_hip.so lacks {missing}"
+    assert set(names) == set(nb.HIP_API), "python binding and header disagree"
+
+
+def test_nbody_library_exports_public_surface():
+    names = declared_functions("nbody.h") + declared_functions("galaxy.h")
+    assert set(names) == {"CreateWorld", "DestroyWorld", "GetWorldParticles", "UpdateWorld_CPU",
+                          "UpdateWorld_GPU", "MakeGalaxies"}   # reference nbody.h:61-73, galaxy.h:64
+    have = exported(nb.NBODY_SO)
+    assert not [n for n in names if n not in have]
+
+
+def test_libraries_load_and_bind():
+    nb.nbody_lib()
+    assert nb.hip_lib().nb_hip_version() >= 100
+    assert nb.device_count() >= 0  # never aborts, also without a GPU
+
+
+def test_hip_library_does_not_link_oracle_or_rccl_eagerly():
+    out = subprocess.run(["ldd", nb.HIP_SO], check=True, capture_output=True, text=True).stdout
+    assert "oracle" not in out and "librccl" not in out
+    out = subprocess.run(["ldd", nb.NBODY_SO], check=True, capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+def test_particle_layout_is_32_bytes():
+    src = r'''
+    #include <stddef.h>
+    #include <stdio.h>
+    #include "nbody.h"
+    #include "nbody_hip.h"
+    int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(Particle), offsetof(Particle,pos), offsetof(Particle,vel),
+      offsetof(Particle,acc), offsetof(Particle,mass), offsetof(Particle,radius), sizeof(WorldData)); return 0; }'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o",
+                        os.path.join(d, "t")], check=True)
+        out = subprocess.run([os.path.join(d, "t")], check=True, capture_output=True, text=True).stdout.split()
+    assert out == ["32", "0", "8", "16", "24", "28", "12"]   # reference nbody.h:47-55, sim_gpu.h:8-12
+
+
+def test_pipeline_create_destroy_needs_no_gpu():
+    L = nb.hip_lib()
+    h = L.CreateSimPipeline(nb.WorldData(1000, 400, 0.0))
+    assert h
+    L.DestroySimPipeline(h)
+    L.DestroySimPipeline(None)   # NULL accepted, reference sim_gpu.c:224
+
+
+@pytest.mark.parametrize("N,M,P", [(1 << 20, 523884, 8), (1 << 20, 523884, 2), (4096, 1989, 4), (333, 150, 8),
+                                   (100, 0, 3), (100, 100, 3), (65, 1, 2), (0, 0, 2), (1 << 22, 2100000, 8)])
+def test_shard_plan_covers_everything_once(N, M, P):
+    plans = [nb.shard_plan(N, M, r, P) for r in range(P)]
+    mc, zc = plans[0]["mass_chunk"], plans[0]["zero_chunk"]
+    assert all(p["mass_chunk"] == mc and p["zero_chunk"] == zc and p["src_padded"] == P * mc for p in plans)
+    assert mc % 64 == 0 and zc % 64 == 0           # wave-aligned, uniform all-gather counts
+    owned = np.zeros(N, dtype=np.int32)
+    for r, p in enumerate(plans):
+        assert p["mass_count"] <= mc and p["zero_count"] <= zc
+        if p["mass_count"]:
+            assert p["mass_begin"] == r * mc       # gathered index == global massive index
+        assert p["mass_begin"] + p["mass_count"] <= M
+        assert M <= p["zero_begin"] and p["zero_begin"] + p["zero_count"] <= N
+        owned[p["mass_begin"]:p["mass_begin"] + p["mass_count"]] += 1
+        owned[p["zero_begin"]:p["zero_begin"] + p["zero_count"]] += 1
+    assert np.all(owned == 1)
+    # balance: every receiver costs the same, so slot counts per rank differ by at most the padding
+    slots = [p["mass_count"] + p["zero_count"] for p in plans]
+    if N >= 64 * P * 4:
+        assert max(slots) - min(slots) <= 128 + (mc * P - M) + (zc * P - (N - M))
+
+
+def test_gpu_call_without_gpu_aborts_loudly():
+    """No CPU fallback: UpdateWorld_GPU on a box without a GPU must abort, not compute."""
+    if nb.device_count() > 0:
+        pytest.skip("a GPU is present")
+    code = ("import numpy as np, nbody_amd as nb\n"
+            "a=np.zeros((8,8),dtype=np.float32); a[:,6]=1; a[:,7]=1\n"
+            "w=nb.World(a); w.update_gpu(0.1,1); print('SURVIVED')\n")
+    r = subprocess.run(["python", "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode != 0 and "SURVIVED" not in r.stdout
+    assert "no HIP device" in r.stderr or "hipError" in r.stderr

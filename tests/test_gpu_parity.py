@@ -1,0 +1,473 @@
+"""Parity of the HIP path with the oracle, through the C-ABI (needs an MI355X: `pytest -m gpu`).
+
+Tolerance (DESIGN.md "Tolerance"): one step from an identical state, per component,
+    |acc_gpu - acc_f64| <= 1e-4 * |acc_f64| + 1e-6 * sum_j |contribution_j|
+where acc_f64 is the oracle's float64 evaluation of the same sum.  The reference's own AVX / SSE / scalar
+builds differ from each other by the same order (2.9e-6 .. 1.4e-5 relative).  The integrator is
+then exact fp32 arithmetic on that acc with the reference's roundings (sim_cpu.c:191-193: mul, then add),
+checked bit for bit: vel == vel0 + acc*dt and pos == pos0 + vel*dt.
+Ten steps at dt = 0.01: relative L2 over all positions <= 1e-6.  Nothing is asserted on 100-step
+trajectories (chaotic).  Integer-like facts (partition order, mass, radius, pass-through) are bit-exact.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import nbody_amd as nb
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(0, 0), (1, 1), (1, 16), (2, 4), (4, 1), (4, 4), (4, 16), (2, 8)]
+
+
+def acc_bound(acc64, mag):
+    return 1e-4 * np.abs(acc64) + 1e-6 * mag
+
+
+def check_one_step(got, part, m, dt, want=None):
+    """got = device state one step after `part`; checks acc against float64 and vel/pos against the AVX path."""
+    acc64, mag = ob.acc_f64(part, m)
+    bound = acc_bound(acc64, mag)
+    err = np.abs(got[:, 4:6].astype(np.float64) - acc64)
+    assert np.all(err <= bound), f"acc outside tolerance: worst ratio {np.max(err / bound):.3f}"
+    # the integrator is exact fp32 arithmetic on the device's own acc, with the reference's roundings
+    # (vel += acc*dt; pos += vel*dt; mul then add, reference sim_cpu.c:191-193): bit-exact
+    v = part[:, 2:4] + got[:, 4:6] * np.float32(dt)
+    p = part[:, 0:2] + v * np.float32(dt)
+    assert np.array_equal(got[:, 2:4], v), "velocity is not vel + acc*dt in fp32"
+    assert np.array_equal(got[:, 0:2], p), "position is not pos + vel*dt in fp32"
+    # against the reference AVX path: both sit within the same bound of the float64 sum
+    if want is None:
+        want = ob.step(part, m, dt, 1)
+    e_ref = np.abs(want[:, 4:6].astype(np.float64) - acc64)
+    assert np.all(np.abs(got[:, 4:6].astype(np.float64) - want[:, 4:6]) <= bound + e_ref)
+    assert np.array_equal(got[:, 6:8], part[:, 6:8]), "mass / radius must pass through untouched"
+
+
+def run(part, m, n, dt, **knobs):
+    sim = nb.SimPipeline(part.shape[0], m)
+    sim.configure(**knobs)
+    sim.set_data(part)
+    sim.update(n, dt)
+    out = sim.get_data()
+    sim.close()
+    return out
+
+
+def synth(n, frac_massive=0.5, seed=0, extent=1.0e4):
+    rng = np.random.default_rng(seed)
+    a = np.zeros((n, 8), dtype=np.float32)
+    a[:, 0:2] = rng.standard_normal((n, 2)) * extent
+    a[:, 2:4] = rng.standard_normal((n, 2)) * 10
+    massive = rng.random(n) < frac_massive
+    a[:, 7] = np.where(massive, 1.5 + 8 * rng.random(n), 0.5)
+    a[:, 6] = np.where(massive, 41.9 * a[:, 7] ** 3, 0.0)
+    return ob.partition(a)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fixtures of the reference (golden vectors)
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("k,w", SHAPES)
+@pytest.mark.parametrize("n", [4096, 333])
+def test_one_step_against_reference_fixture(golden, manifest, n, k, w, variant):
+    part, m = ob.partition(golden(f"ic_{n}.bin"))
+    e = manifest["sets"][str(n)]["steps"]
+    got = run(part, m, 1, 0.01, variant=variant, k=k, w=w)
+    want = golden(e["s1_dt0.01"]["file"]) if "s1_dt0.01" in e else None
+    check_one_step(got, part, m, 0.01, want)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("n", [4096, 1024])
+def test_ten_steps_against_reference_fixture(golden, manifest, n, variant):
+    part, m = ob.partition(golden(f"ic_{n}.bin"))
+    want = golden(manifest["sets"][str(n)]["steps"]["s10_dt0.01"]["file"]).astype(np.float64)
+    got = run(part, m, 10, 0.01, variant=variant).astype(np.float64)
+    rel = np.linalg.norm(got[:, 0:2] - want[:, 0:2]) / np.linalg.norm(want[:, 0:2])
+    assert rel <= 1e-6, rel
+    relv = np.linalg.norm(got[:, 2:4] - want[:, 2:4]) / np.linalg.norm(want[:, 2:4])
+    assert relv <= 1e-5, relv
+
+
+def test_three_steps_dt005_fixture(golden, manifest):
+    part, m = ob.partition(golden("ic_333.bin"))
+    want = golden(manifest["sets"]["333"]["steps"]["s3_dt0.05"]["file"]).astype(np.float64)
+    got = run(part, m, 3, 0.05).astype(np.float64)
+    assert np.linalg.norm(got[:, 0:2] - want[:, 0:2]) / np.linalg.norm(want[:, 0:2]) <= 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the World surface and the coherence protocol (reference world.c:76-118, main.c:112-163 call pattern)
+# ---------------------------------------------------------------------------------------------------------------
+
+def test_world_gpu_equals_seam(golden):
+    ic = golden("ic_1024.bin")
+    part, m = ob.partition(ic)
+    w = nb.World(ic)
+    assert np.array_equal(w.particles(), part)
+    w.update_gpu(0.01, 3)
+    a = w.particles()
+    w.close()
+    assert a.tobytes() == run(part, m, 3, 0.01).tobytes()
+
+
+def test_world_gpu_zero_steps_is_a_noop(golden):
+    w = nb.World(golden("ic_333.bin"))
+    before = w.particles()
+    w.update_gpu(0.01, 0)      # reference world.c:113
+    assert np.array_equal(w.particles(), before)
+    w.close()
+
+
+def test_mixed_cpu_gpu_calls_keep_one_state(golden):
+    ic = golden("ic_1024.bin")
+    part, m = ob.partition(ic)
+    w = nb.World(ic)
+    w.update_gpu(0.01, 2)
+    g2 = w.particles()                       # D2H on demand
+    w.update_cpu(0.01, 0)                    # n == 0 still syncs and dirties (world.c:100,109)
+    assert np.array_equal(w.particles(), g2)
+    w.update_cpu(0.01, 1)                    # CPU continues from the device state
+    c3 = w.particles()
+    assert np.array_equal(c3, ob.step(g2, m, 0.01, 1))   # CPU path is bit-exact from whatever state it gets
+    w.update_gpu(0.02, 1)                    # H2D of the CPU-dirtied array, new dt
+    g4 = w.particles()
+    w.close()
+    check_one_step(g4, c3, m, 0.02)
+    check_one_step(run(part, m, 1, 0.01), part, m, 0.01)
+
+
+def test_read_back_every_frame_equals_one_call(golden):
+    part, m = ob.partition(golden("ic_333.bin"))
+    sim = nb.SimPipeline(333, m)
+    sim.set_data(part)
+    for _ in range(5):
+        sim.update(1, 0.01)
+        sim.get_data()
+    a = sim.get_data()
+    sim.close()
+    assert a.tobytes() == run(part, m, 5, 0.01).tobytes()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# step chains: hipGraph vs plain launches, phases, dt patching
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n_steps", [1, 2, 3, 7, 64, 65, 130])
+def test_graph_chain_equals_plain_launches(golden, n_steps):
+    part, m = ob.partition(golden("ic_333.bin"))
+    a = run(part, m, n_steps, 0.01, graph=1)
+    b = run(part, m, n_steps, 0.01, graph=0)
+    assert a.tobytes() == b.tobytes()
+
+
+def test_split_calls_and_odd_phases(golden):
+    part, m = ob.partition(golden("ic_333.bin"))
+    want = run(part, m, 12, 0.01, graph=0)
+    sim = nb.SimPipeline(333, m)
+    sim.set_data(part)
+    for n in (3, 3, 1, 5):       # same chain length reused on the other ping-pong phase
+        sim.update(n, 0.01)
+    got = sim.get_data()
+    sim.close()
+    assert got.tobytes() == want.tobytes()
+
+
+def test_dt_change_patches_the_cached_chain(golden):
+    part, m = ob.partition(golden("ic_333.bin"))
+    sim = nb.SimPipeline(333, m)
+    sim.set_data(part)
+    sim.update(4, 0.01)
+    sim.update(4, 0.005)         # same n, dt halved: kernel-node parameters are rewritten
+    sim.update(4, 0.01)
+    got = sim.get_data()
+    sim.close()
+    ref = nb.SimPipeline(333, m)
+    ref.configure(graph=0)
+    ref.set_data(part)
+    for dt in (0.01, 0.005, 0.01):
+        ref.update(4, dt)
+    want = ref.get_data()
+    ref.close()
+    assert got.tobytes() == want.tobytes()
+
+
+def test_set_data_again_restarts_from_the_new_state(golden):
+    part, m = ob.partition(golden("ic_333.bin"))
+    sim = nb.SimPipeline(333, m)
+    sim.set_data(part)
+    sim.update(3, 0.01)
+    sim.set_data(part)
+    sim.update(2, 0.01)
+    got = sim.get_data()
+    sim.close()
+    assert got.tobytes() == run(part, m, 2, 0.01).tobytes()
+
+
+def test_async_steps_then_sync(golden):
+    part, m = ob.partition(golden("ic_333.bin"))
+    sim = nb.SimPipeline(333, m)
+    sim.set_data(part)
+    sim.step_async(2, 0.01)
+    sim.step_async(3, 0.01)
+    sim.sync()
+    ms, launches = sim.last_step_ms()
+    got = sim.get_data()
+    sim.close()
+    assert launches == 3 and ms > 0
+    assert got.tobytes() == run(part, m, 5, 0.01).tobytes()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# kernel properties: determinism, variants, linearity, edge shapes
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("k,w", [(1, 1), (2, 4), (4, 16)])
+def test_lds_and_smem_variants_agree_bitwise(golden, k, w):
+    # same source order per wave slice; the LDS tail tile's zero-mass pads add exact zeros
+    part, m = ob.partition(golden("ic_4096.bin"))
+    a = run(part, m, 2, 0.01, variant=0, k=k, w=w)
+    b = run(part, m, 2, 0.01, variant=1, k=k, w=w)
+    assert a.tobytes() == b.tobytes()
+
+
+def test_deterministic(golden):
+    part, m = ob.partition(golden("ic_4096.bin"))
+    assert run(part, m, 3, 0.01).tobytes() == run(part, m, 3, 0.01).tobytes()
+
+
+def test_k_does_not_change_bits(golden):
+    # register blocking regroups receivers, never the order sources are added in
+    part, m = ob.partition(golden("ic_1024.bin"))
+    a = run(part, m, 1, 0.01, k=1, w=4)
+    for k in (2, 4):
+        assert run(part, m, 1, 0.01, k=k, w=4).tobytes() == a.tobytes()
+
+
+def test_acc_is_linear_in_mass_by_powers_of_two(golden):
+    part, m = ob.partition(golden("ic_1024.bin"))
+    heavy = part.copy()
+    heavy[:, 6] *= 4.0
+    a = run(part, m, 1, 0.01)[:, 4:6]
+    b = run(heavy, m, 1, 0.01)[:, 4:6]
+    assert np.array_equal(b, a * np.float32(4.0))
+
+
+@pytest.mark.parametrize("n,frac", [(1, 1.0), (2, 0.5), (63, 0.5), (64, 1.0), (65, 0.3), (130, 1.0), (257, 0.02),
+                                    (1000, 0.0), (4097, 0.7)])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_ragged_sizes_and_source_counts(n, frac, variant):
+    part, m = synth(n, frac, seed=n)
+    if frac == 1.0:
+        assert m == n
+    got = run(part, m, 1, 0.02, variant=variant)
+    check_one_step(got, part, m, 0.02)
+
+
+def test_no_sources_means_straight_lines():
+    part, m = synth(500, 0.0, seed=9)
+    assert m == 0
+    got = run(part, m, 2, 0.5)
+    want = ob.step(part, 0, 0.5, 2)
+    assert got.tobytes() == want.tobytes()
+
+
+def test_single_source_known_answer():
+    # one core at the origin, one tracer at (3, 4): |d|^2 + radius = 25 + 0 ... use radius 11 -> r2 = 36
+    a = np.zeros((2, 8), dtype=np.float32)
+    a[0, 6], a[0, 7] = 21.6, 1.0           # G*m = 216
+    a[1, 0], a[1, 1], a[1, 7] = 3.0, 4.0, 11.0
+    got = run(a, 1, 1, 1.0)
+    # f = 216 / 36^1.5 = 1 -> acc = -(3, 4)
+    assert np.allclose(got[1, 4:6], [-3.0, -4.0], rtol=1e-6, atol=0)
+    assert got[0, 4] == 0 and got[0, 5] == 0   # self-interaction contributes exactly zero
+    assert np.allclose(got[1, 0:2], [0.0, 0.0], atol=1e-6)
+
+
+def test_negative_mass_is_massless():
+    a = np.zeros((3, 8), dtype=np.float32)
+    a[:, 7] = 1.0
+    a[:, 6] = [5.0, -3.0, 0.0]
+    a[:, 0] = [0.0, 10.0, 20.0]
+    w = nb.World(a)                          # partition uses > 0 / <= 0 (reference world.c:35-36)
+    w.update_gpu(0.1, 1)
+    got = w.particles()
+    w.close()
+    assert got[0, 6] == 5.0 and got[0, 4] == 0.0
+    assert np.all(got[1:, 4] < 0)            # both tracers fall towards the single source, nothing else pulls
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json sizes: spot-checked against float64 on a receiver sample + size-independent properties
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n,steps,dt", [(65536, 1, 0.01), (262144, 4, 0.005), (1 << 20, 1, 0.01)])
+def test_baseline_sizes_spot_check(n, steps, dt):
+    ic = nb.make_galaxies(n, 2, seed=11037)          # the bench's universe
+    w = nb.World(ic)
+    part = w.particles()
+    m = int((part[:, 6] > 0).sum())
+    w.close()
+    sim = nb.SimPipeline(n, m)
+    sim.set_data(part)
+    sim.update(1, dt)
+    one = sim.get_data()
+    rng = np.random.default_rng(n)
+    idx = np.unique(np.concatenate([[0, 1, m - 1, m, n - 1], rng.integers(0, n, 500)])).astype(np.uint32)
+    acc64, mag = ob.acc_f64_subset(part, m, idx)
+    err = np.abs(one[idx, 4:6].astype(np.float64) - acc64)
+    bound = acc_bound(acc64, mag)
+    assert np.all(err <= bound), f"worst ratio {np.max(err / bound):.3f}"
+    # tie-breaker: the device sum is closer to float64 than the reference's AVX sum is
+    e_avx = np.abs(ob.acc_avx_subset(part, m, idx).astype(np.float64) - acc64)
+    assert np.sqrt(np.mean((err / mag) ** 2)) <= np.sqrt(np.mean((e_avx / mag) ** 2))
+    assert np.all(np.abs(one[idx, 4:6].astype(np.float64) - ob.acc_avx_subset(part, m, idx)) <= bound + e_avx)
+    # integrator exactness on the device's own acc (mul, add roundings of the reference)
+    v = part[:, 2:4] + one[:, 4:6] * np.float32(dt)
+    p = part[:, 0:2] + v * np.float32(dt)
+    assert np.array_equal(one[:, 2:4], v) and np.array_equal(one[:, 0:2], p)
+    if steps > 1:
+        sim.update(steps - 1, dt)                     # multi-step hipGraph chain (config 3)
+        chained = sim.get_data()
+        sim.set_data(part)
+        sim.configure(graph=0)
+        sim.update(steps, dt)
+        assert sim.get_data().tobytes() == chained.tobytes()
+    sim.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sharded pipeline on one GPU: local transport (all ranks in this process) and RCCL with one rank
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("P", [2, 3, 8])
+@pytest.mark.parametrize("n", [4096, 333])
+def test_local_shard_group_single_slice_is_bitwise_equal(golden, n, P):
+    # w = 1: every receiver adds the sources in index order, pads add exact zeros -> same bits as one GPU
+    part, m = ob.partition(golden(f"ic_{n}.bin"))
+    want = run(part, m, 3, 0.01, w=1, k=1)
+    g = nb.LocalShardGroup(n, m, P, w=1, k=1)
+    g.set_data(part)
+    g.step(3, 0.01)
+    outs = [g.get_data(r) for r in range(P)]
+    g.close()
+    for o in outs:
+        assert o.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("overlap", [0, 1])
+@pytest.mark.parametrize("P", [2, 8])
+def test_local_shard_group_default_shape_within_tolerance(golden, P, overlap):
+    part, m = ob.partition(golden("ic_4096.bin"))
+    g = nb.LocalShardGroup(4096, m, P, overlap=overlap)
+    g.set_data(part)
+    g.step(1, 0.01)
+    got = g.get_data(P - 1)
+    g.step(9, 0.01)
+    ten = g.get_data(0).astype(np.float64)
+    g.close()
+    check_one_step(got, part, m, 0.01)
+    want = ob.step(part, m, 0.01, 10).astype(np.float64)
+    assert np.linalg.norm(ten[:, 0:2] - want[:, 0:2]) / np.linalg.norm(want[:, 0:2]) <= 1e-6
+
+
+def test_local_shard_group_ragged(golden):
+    part, m = synth(1000, 0.013, seed=4)      # 13 sources over 4 ranks: some ranks own no source
+    g = nb.LocalShardGroup(1000, m, 4)
+    g.set_data(part)
+    g.step(1, 0.02)
+    got = g.get_data(2)
+    g.close()
+    check_one_step(got, part, m, 0.02)
+
+
+def test_rccl_path_with_one_rank_in_a_subprocess(golden, tmp_path):
+    """NB_HIP_FORCE_SHARDED=1: dlopen librccl, ncclCommInitRank(1 rank), in-place all-gathers, both step modes."""
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, %(root)r)
+import nbody_amd as nb, oracle_binding as ob
+ic = np.fromfile(os.path.join(%(root)r, "tests/golden/ic_1024.bin"), dtype=np.float32).reshape(-1, 8)
+part, m = ob.partition(ic)
+uid = nb.comm_unique_id()
+L = nb.hip_lib()
+outs = []
+for overlap in (0, 1):
+    sim = nb.SimPipeline.__new__(nb.SimPipeline)
+    import ctypes as C
+    buf = (C.c_ubyte * 128).from_buffer_copy(uid if overlap == 0 else nb.comm_unique_id())
+    sim._h = L.CreateSimPipelineSharded(nb.WorldData(1024, m, 0.0), 0, 1, buf)
+    sim.total_len, sim.mass_len, sim.rank, sim.nranks = 1024, m, 0, 1
+    sim.configure(w=1, k=1, overlap=overlap)
+    sim.set_data(part); sim.update(3, 0.01); outs.append(sim.get_data()); sim.close()
+plain = nb.SimPipeline(1024, m); plain.configure(w=1, k=1); plain.set_data(part); plain.update(3, 0.01)
+want = plain.get_data(); plain.close()
+assert outs[0].tobytes() == want.tobytes(), "rccl 1-rank path differs"
+assert outs[1].tobytes() == want.tobytes(), "rccl 1-rank overlap path differs"
+print("RCCL-ONE-RANK-OK")
+''' % {"root": nb.ROOT}
+    env = dict(os.environ, NB_HIP_FORCE_SHARDED="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# drop-in: the reference's own world.c / bench.c on top of libnbody_hip.so (oracle/_ref travels prebuilt)
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.skipif(not os.path.exists(ob.REF_WORLD_SO), reason="oracle/_ref/libnbody_ref_world.so not built")
+def test_reference_world_c_drives_our_hip_pipeline(golden):
+    nb.hip_lib()
+    ref = C.CDLL(ob.REF_WORLD_SO)
+    ref.CreateWorld.restype = C.c_void_p
+    ref.CreateWorld.argtypes = [C.c_void_p, C.c_uint32]
+    ref.GetWorldParticles.restype = C.c_void_p
+    ref.GetWorldParticles.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    ref.UpdateWorld_GPU.argtypes = [C.c_void_p, C.c_float, C.c_uint32]
+    ref.UpdateWorld_CPU.argtypes = [C.c_void_p, C.c_float, C.c_uint32]
+    ref.DestroyWorld.argtypes = [C.c_void_p]
+    ic = golden("ic_1024.bin")
+    w = ref.CreateWorld(ic.ctypes.data, 1024)
+    ref.UpdateWorld_GPU(w, 0.01, 2)
+    ref.UpdateWorld_CPU(w, 0.01, 1)
+    ref.UpdateWorld_GPU(w, 0.01, 1)
+    n = C.c_uint32()
+    p = ref.GetWorldParticles(w, C.byref(n))
+    got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n.value, 8)).copy()
+    ref.DestroyWorld(w)
+    ours = nb.World(ic)
+    ours.update_gpu(0.01, 2)
+    ours.update_cpu(0.01, 1)
+    ours.update_gpu(0.01, 1)
+    want = ours.particles()
+    ours.close()
+    assert got.tobytes() == want.tobytes()
+
+
+def test_nbody_bench_gpu_column():
+    exe = os.path.join(nb.LIB_DIR, "nbody-bench")
+    r = subprocess.run([exe, "--gpu", "--n", "4000", "--n", "20000", "--steps", "10", "--warmup", "2", "--dt", "0.01"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [l.split() for l in r.stdout.strip().splitlines()]
+    assert rows[0][:2] == ["N", "GPU"] and [x[0] for x in rows[1:]] == ["4000", "20000"]
+    assert all(float(x[2]) > 1e9 for x in rows[1:])
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ob.ORACLE_DIR, "_ref", "nbody-bench-ref")),
+                    reason="oracle/_ref/nbody-bench-ref not built")
+def test_reference_bench_c_runs_unchanged_on_our_library():
+    exe = os.path.join(ob.ORACLE_DIR, "_ref", "nbody-bench-ref")
+    r = subprocess.run([exe, "--gpu"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [l.split() for l in r.stdout.strip().splitlines()]
+    assert rows[0] == ["N", "GPU"]
+    assert [int(x[0]) for x in rows[1:]] == [250, 500, 800, 1200, 2000, 4000, 10000, 20000, 50000, 100000]
