@@ -102,7 +102,7 @@ double nb_hip_last_step_ms(SimPipeline *sim, uint32_t *launches);
 
 /*
  * Tuning knobs.  key is one of:
- *   "variant"   0 = wave-private LDS tiles (default), 1 = scalar-cache (SMEM) source broadcast
+ *   "variant"   0 = wave-private LDS tiles, 1 = scalar-cache (SMEM) source broadcast (default: measured faster)
  *   "k"         receivers per lane: 0 = auto, else 1, 2 or 4
  *   "w"         waves (source slices) per workgroup: 0 = auto, else 1, 2, 4, 8 or 16
  *   "graph"     1 = run step chains as hipGraphs (default), 0 = plain stream launches

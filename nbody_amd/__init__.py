@@ -17,7 +17,7 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 LIB_DIR = os.path.join(PKG_DIR, "lib")
-HIP_SO = os.path.join(LIB_DIR, "libnbody_hip.so")
+HIP_SO = os.environ.get("NBODY_HIP_SO") or os.path.join(LIB_DIR, "libnbody_hip.so")  # override: kernel experiments
 NBODY_SO = os.path.join(LIB_DIR, "libnbody.so")
 
 NB_G = 10.0

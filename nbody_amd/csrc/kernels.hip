@@ -70,6 +70,16 @@ __device__ __forceinline__ void interact(Receivers<K> &R, float sx, float sy, fl
     }
 }
 
+// 8 sources (x,y interleaved in P, G*m in G) against the K receivers.  The order of the 80*K VALU
+// instructions is left to the compiler: forcing the 8*K v_rsq_f32 into back-to-back runs with
+// sched_barrier phases measured 7-8 % slower (profiles/r01_sweep1_grouping_slp.txt), although isolated
+// runs of transcendentals are cheaper than sprinkled ones (profiles/r01_ubench2_rsq_mixing.txt).
+template <int K, typename VP, typename VG>
+__device__ __forceinline__ void interact8(Receivers<K> &R, const VP &P, const VG &G) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) interact<K>(R, P[2 * u], P[2 * u + 1], G[u]);
+}
+
 // Map a position v of the concatenated source ranges to an index of src_pos/src_gm.
 __device__ __forceinline__ uint32_t source_index(const StepParams &p, uint32_t v, uint32_t n0) {
     return v < n0 ? p.src_begin[0] + v : p.src_begin[1] + (v - n0);
@@ -129,15 +139,17 @@ __global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 2
-            for (int jj = 0; jj < CHUNK; jj += 4) {
-                const float4 X = *reinterpret_cast<const float4 *>(&T[buf][0][jj]);  // broadcast ds_read_b128
-                const float4 Y = *reinterpret_cast<const float4 *>(&T[buf][1][jj]);
-                const float4 G = *reinterpret_cast<const float4 *>(&T[buf][2][jj]);
-                interact<K>(R, X.x, Y.x, G.x);
-                interact<K>(R, X.y, Y.y, G.y);
-                interact<K>(R, X.z, Y.z, G.z);
-                interact<K>(R, X.w, Y.w, G.w);
+            for (int jj = 0; jj < CHUNK; jj += 8) {
+                const float4 X0 = *reinterpret_cast<const float4 *>(&T[buf][0][jj]);  // broadcast ds_read_b128
+                const float4 X1 = *reinterpret_cast<const float4 *>(&T[buf][0][jj + 4]);
+                const float4 Y0 = *reinterpret_cast<const float4 *>(&T[buf][1][jj]);
+                const float4 Y1 = *reinterpret_cast<const float4 *>(&T[buf][1][jj + 4]);
+                const float4 G0 = *reinterpret_cast<const float4 *>(&T[buf][2][jj]);
+                const float4 G1 = *reinterpret_cast<const float4 *>(&T[buf][2][jj + 4]);
+                const float P[16] = {X0.x, Y0.x, X0.y, Y0.y, X0.z, Y0.z, X0.w, Y0.w,
+                                     X1.x, Y1.x, X1.y, Y1.y, X1.z, Y1.z, X1.w, Y1.w};
+                const float G[8] = {G0.x, G0.y, G0.z, G0.w, G1.x, G1.y, G1.z, G1.w};
+                interact8<K>(R, P, G);
             }
             R.close_chunk();
             buf ^= 1;
@@ -173,8 +185,7 @@ __global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
                         P = *reinterpret_cast<const v16f *>(sp + 2 * (size_t)j);
                         G = *reinterpret_cast<const v8f *>(sg + j);
                     }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) interact<K>(R, Pc[2 * u], Pc[2 * u + 1], Gc[u]);
+                    interact8<K>(R, Pc, Gc);
                     if ((g & 7u) == 7u) R.close_chunk();
                 }
             }

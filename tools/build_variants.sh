@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build experimental variants of libnbody_hip.so into tools/exp/<name>/ (kernel tuning only).
+set -e
+cd "$(dirname "$0")/.."
+build() { # name, extra flags
+  name=$1; shift
+  mkdir -p tools/exp/$name
+  for f in kernels pipeline; do
+    /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -std=c++17 -Iinclude -Inbody_amd/csrc "$@" -c nbody_amd/csrc/$f.hip -o tools/exp/$name/$f.o &
+  done
+  wait
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o tools/exp/$name/libnbody_hip.so tools/exp/$name/kernels.o tools/exp/$name/pipeline.o -ldl
+  rm tools/exp/$name/*.o
+}
+for spec in "$@"; do
+  name=${spec%%:*}; flags=${spec#*:}
+  build $name $flags
+done
