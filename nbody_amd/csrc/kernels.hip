@@ -12,8 +12,9 @@
 //                     component; double-buffered, no workgroup barrier in the loop;
 //       VARIANT_SMEM  the wave reads its slice through the scalar cache (s_load_dwordx8/x16) so sources
 //                     arrive in SGPRs and feed the VALU as scalar operands; no LDS, no VGPR staging;
-//   * per interaction: 2 sub, 2 fma (dist^2 + receiver radius), v_rsq_f32, 3 mul, 2 fma = 10 VALU issues
-//     against the reference's 14 counted flops (SURVEY.md 8d keeps 14 as the roofline convention);
+//   * per interaction: v_pk_add (dx,dy), 2 fma (dist^2 + receiver radius), v_rsq_f32, 3 mul, v_pk_fma into the
+//     accumulator pair = 8 VALU instructions (10 scalar-equivalent) against the reference's 14 counted flops
+//     (SURVEY.md 8d keeps 14 as the roofline convention);
 //   * the integrator keeps the reference's rounding (mul, then add; sim_cpu.c:191-193 /
 //     particle_cs.glsl:51-52), the force loop does not (rsq + fma instead of sqrt, div, mul, add):
 //     DESIGN.md states the tolerance.
@@ -62,9 +63,14 @@ __device__ __forceinline__ void interact(Receivers<K> &R, float sx, float sy, fl
         float d2 = __builtin_fmaf(dx, dx, R.r[k]);  // softening: + radius of the RECEIVER, not squared
         d2 = __builtin_fmaf(dy, dy, d2);
         const float inv = __builtin_amdgcn_rsqf(d2);  // v_rsq_f32, 1 ulp
-        const float inv2 = inv * inv;
-        const float gi = sg * inv;
-        const float f = gi * inv2;  // G*m / dist^3
+        // G*m / dist^3 as three plain v_mul_f32, pinned with asm: left alone, hipcc's SLP pass pairs them into
+        // two v_pk_mul_f32 (one of them computing f twice) plus a v_mov of G*m into a VGPR, which is 4-5 %
+        // slower (profiles/r01_sweep2_asm_mul.txt).  The asm statements are pure (not volatile) and carry no
+        // memory, so the scheduler still moves them freely.
+        float gi, inv2, f;
+        asm("v_mul_f32 %0, %1, %2" : "=v"(gi) : "s"(sg), "v"(inv));  // G*m stays in its SGPR
+        asm("v_mul_f32 %0, %1, %1" : "=v"(inv2) : "v"(inv));
+        asm("v_mul_f32 %0, %1, %2" : "=v"(f) : "v"(gi), "v"(inv2));
         R.ax[k] = __builtin_fmaf(dx, f, R.ax[k]);
         R.ay[k] = __builtin_fmaf(dy, f, R.ay[k]);
     }
@@ -310,15 +316,10 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, int compute_units) {
     LaunchShape s = want;
     if (compute_units <= 0) compute_units = 256;
     if (s.k == 0) {
-        // deepest register blocking that still gives every CU a workgroup (measured: profiles/r01_probe1)
-        s.k = 1;
-        for (int k = 4; k >= 1; k /= 2) {
-            const uint32_t groups = (n_recv + WAVE * k - 1) / (WAVE * k);
-            if (groups >= (uint32_t)compute_units) {
-                s.k = k;
-                break;
-            }
-        }
+        // two receivers per lane once that still leaves two workgroups per CU; four cost occupancy (71 VGPRs)
+        // and one is 8 % slower at large N (profiles/r01_sweep4_shapes_by_n.txt)
+        const uint32_t groups2 = (n_recv + WAVE * 2 - 1) / (WAVE * 2);
+        s.k = groups2 >= 2u * (uint32_t)compute_units ? 2 : 1;
     }
     if (s.w == 0) {
         // 16 source slices per workgroup: fastest at every size measured, and the shortest fp32 sums
