@@ -37,8 +37,8 @@ template <int K>
 struct Receivers {
     float x[K], y[K], r[K];
     float ax[K], ay[K];  // running sums of the current 64-source chunk
-    float sx[K], sy[K];  // sums of the finished chunks (two-level summation keeps fp32 sums of 10^5..10^6
-                         // terms about as accurate as the reference's 8-lane AVX sums, for 2 adds per chunk)
+    float sx[K], sy[K];  // sums of the finished chunks: two-level summation keeps fp32 sums of 10^5..10^6 terms
+                         // ~200x closer to float64 than the reference's 8-lane AVX sums, for 2 adds per chunk
     __device__ __forceinline__ void clear() {
 #pragma unroll
         for (int k = 0; k < K; k++) ax[k] = ay[k] = sx[k] = sy[k] = 0.0f;
@@ -64,13 +64,16 @@ __device__ __forceinline__ void interact(Receivers<K> &R, float sx, float sy, fl
         d2 = __builtin_fmaf(dy, dy, d2);
         const float inv = __builtin_amdgcn_rsqf(d2);  // v_rsq_f32, 1 ulp
         // G*m / dist^3 as three plain v_mul_f32, pinned with asm: left alone, hipcc's SLP pass pairs them into
-        // two v_pk_mul_f32 (one of them computing f twice) plus a v_mov of G*m into a VGPR, which is 4-5 %
-        // slower (profiles/r01_sweep2_asm_mul.txt).  The asm statements are pure (not volatile) and carry no
-        // memory, so the scheduler still moves them freely.
-        float gi, inv2, f;
-        asm("v_mul_f32 %0, %1, %2" : "=v"(gi) : "s"(sg), "v"(inv));  // G*m stays in its SGPR
-        asm("v_mul_f32 %0, %1, %1" : "=v"(inv2) : "v"(inv));
-        asm("v_mul_f32 %0, %1, %2" : "=v"(f) : "v"(gi), "v"(inv2));
+        // two v_pk_mul_f32 (one of them computing f twice) plus a v_mov of G*m into a VGPR, which is slower
+        // (profiles/r01_sweep5_asm_mul_hazard_fixed.txt: +1.7 % SMEM, +11 % LDS).  gfx950 needs one wait state
+        // between a transcendental and a VALU instruction that reads its result; hipcc pads that for its own
+        // instructions but cannot see into an asm statement, so the statement carries its own s_nop (without
+        // it some lanes read a stale `inv`: the parity tests caught exactly that).  `sg` is wave-uniform in
+        // both variants ("s": the LDS route gets a v_readfirstlane).
+        float inv2, f;
+        asm("s_nop 0\n\tv_mul_f32 %1, %3, %3\n\tv_mul_f32 %0, %2, %3\n\tv_mul_f32 %0, %0, %1"
+            : "=&v"(f), "=&v"(inv2)
+            : "s"(sg), "v"(inv));
         R.ax[k] = __builtin_fmaf(dx, f, R.ax[k]);
         R.ay[k] = __builtin_fmaf(dy, f, R.ay[k]);
     }
