@@ -133,13 +133,18 @@ def main():
 
     import nbody_amd as nb  # loads libnbody_hip.so; aborts later if no gfx950 answers
 
+    # torch.distributed only when launched through torch.distributed.run (also at world == 1, so that a
+    # single-GPU box can rehearse the whole multi-rank flow with NB_HIP_FORCE_SHARDED=1)
     dist = None
-    if world > 1:
+    sharded = world > 1 or os.environ.get("NB_HIP_FORCE_SHARDED", "0") not in ("", "0")
+    if "RANK" in os.environ and "MASTER_PORT" in os.environ:
         import torch
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    elif world > 1:
+        sys.exit("WORLD_SIZE > 1 without a torch.distributed.run rendezvous (RANK / MASTER_PORT missing)")
 
     def barrier():
         if dist is not None:
@@ -150,16 +155,18 @@ def main():
     n = part.shape[0]
 
     uid = None
-    if world > 1:
-        import torch
+    if sharded:
+        # rank 0 makes the RCCL unique id; gloo carries its 128 bytes to the other ranks
+        raw = bytearray(nb.comm_unique_id()) if rank == 0 else bytearray(nb.UNIQUE_ID_BYTES)
+        if dist is not None:
+            import torch
 
-        buf = torch.zeros(nb.UNIQUE_ID_BYTES, dtype=torch.uint8)
-        if rank == 0:
-            buf = torch.frombuffer(bytearray(nb.comm_unique_id()), dtype=torch.uint8).clone()
-        dist.broadcast(buf, src=0)
-        uid = bytes(buf.numpy().tobytes())
+            buf = torch.frombuffer(raw, dtype=torch.uint8).clone()
+            dist.broadcast(buf, src=0)
+            raw = bytearray(buf.numpy().tobytes())
+        uid = bytes(raw)
 
-    sim = nb.SimPipeline(n, mass_len, rank=rank, nranks=world, unique_id=uid)
+    sim = nb.SimPipeline(n, mass_len, rank=rank, nranks=world, unique_id=uid if sharded else None)
     sim.set_data(part)           # H2D + SoA split: outside the timed region
 
     if args.warmup > 0:

@@ -139,7 +139,7 @@ class SimPipeline:
     def __init__(self, total_len, mass_len, rank=0, nranks=1, unique_id=None):
         L = hip_lib()
         wd = WorldData(total_len, mass_len, 0.0)
-        if nranks > 1:
+        if nranks > 1 or unique_id is not None:
             idbuf = (C.c_ubyte * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
             self._h = L.CreateSimPipelineSharded(wd, rank, nranks, idbuf)
         else:
