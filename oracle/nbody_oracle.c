@@ -148,6 +148,63 @@ static void receiver_avx_order(Particle *p, const Snapshot *s, float dt) {
     integrate(p, sx, sy, dt);
 }
 
+/*
+ * The reference's three SIMD_SET builds differ only in the pack width L (sim_cpu.c:27,56,77: 8, 4, 1):
+ * element e of the accumulator takes sources j with j mod L == L-1-e (SIMD_SET_ARR puts P[0] in the top
+ * element), the tail pack is zero-filled, and simd_sum adds elements 0..L-1.  L = 1 is the scalar build.
+ */
+static void receiver_lanes(Particle *p, const float *sx, const float *sy, const float *sm, uint32_t padded,
+                           uint32_t L, float dt) {
+    const float g = NB_G;
+    const float x = p->pos.x, y = p->pos.y, r = p->radius;
+    float ax[LANES], ay[LANES];
+    for (uint32_t e = 0; e < L; e++) ax[e] = ay[e] = 0.0f;
+    for (uint32_t base = 0; base < padded; base += L) {
+        for (uint32_t k = 0; k < L; k++) {
+            const uint32_t e = L - 1u - k, j = base + k;
+            float dx = sx[j] - x;
+            float dy = sy[j] - y;
+            float xx = dx * dx;
+            float yy = dy * dy;
+            float r2 = (xx + yy) + r;
+            float r1 = sqrtf(r2);
+            float gm = sm[j] * g;
+            float r3 = r1 * r2;
+            float f = gm / r3;
+            float cx = dx * f;
+            float cy = dy * f;
+            ax[e] = ax[e] + cx;
+            ay[e] = ay[e] + cy;
+        }
+    }
+    float tx = 0.0f, ty = 0.0f;
+    for (uint32_t e = 0; e < L; e++) tx += ax[e];
+    for (uint32_t e = 0; e < L; e++) ty += ay[e];
+    integrate(p, tx, ty, dt);
+}
+
+void orc_step_lanes(Particle *arr, uint32_t total_len, uint32_t mass_len, float dt, uint32_t n, uint32_t lanes) {
+    if (lanes != 1 && lanes != 4 && lanes != 8) abort();
+    const uint32_t padded = (mass_len + lanes - 1u) / lanes * lanes;
+    float *sx = (float *)malloc((size_t)(padded + 1) * sizeof(float));
+    float *sy = (float *)malloc((size_t)(padded + 1) * sizeof(float));
+    float *sm = (float *)malloc((size_t)(padded + 1) * sizeof(float));
+    if (!sx || !sy || !sm) abort();
+    for (uint32_t it = 0; it < n; it++) {
+        for (uint32_t j = 0; j < padded; j++) {
+            const int live = j < mass_len;
+            sx[j] = live ? arr[j].pos.x : 0.0f;
+            sy[j] = live ? arr[j].pos.y : 0.0f;
+            sm[j] = live ? arr[j].mass : 0.0f;
+        }
+#pragma omp parallel for schedule(static, 20)
+        for (uint32_t i = 0; i < total_len; i++) receiver_lanes(&arr[i], sx, sy, sm, padded, lanes, dt);
+    }
+    free(sx);
+    free(sy);
+    free(sm);
+}
+
 void orc_step_avx_order(Particle *arr, uint32_t total_len, uint32_t mass_len, float dt, uint32_t n) {
     Snapshot s = snapshot_alloc(mass_len);
     for (uint32_t it = 0; it < n; it++) {

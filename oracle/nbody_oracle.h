@@ -37,6 +37,12 @@ uint32_t orc_partition_ints(int *arr, uint32_t size);
  */
 void orc_step_avx_order(Particle *arr, uint32_t total_len, uint32_t mass_len, float dt, uint32_t n);
 
+/*
+ * The reference's other SIMD_SET builds (src/lib/CMakeLists.txt:24-33): lanes = 4 is the SSE build
+ * (sim_cpu.c:46-68), lanes = 1 the scalar one (sim_cpu.c:70-91), lanes = 8 equals orc_step_avx_order.
+ */
+void orc_step_lanes(Particle *arr, uint32_t total_len, uint32_t mass_len, float dt, uint32_t n, uint32_t lanes);
+
 /* the same arithmetic written with AVX intrinsics + OpenMP: the timed "port" CPU baseline */
 void orc_step_avx(Particle *arr, uint32_t total_len, uint32_t mass_len, float dt, uint32_t n);
 

@@ -77,7 +77,7 @@ def main():
         return a
 
     def ref_steps(arr, m, dt, nsteps):
-        """world.c:99-110 with the reference's own PackParticles/PackedUpdate."""
+        """world.c:99-110 with the reference's own PackParticles/PackedUpdate (of whichever build `ref` is)."""
         arr = arr.copy()
         n = arr.shape[0]
         pack = C.c_void_p()
@@ -111,6 +111,30 @@ def main():
                 entry["steps"][tag]["file"] = f"ref_avx_{n}_{tag}.bin"
             print(f"N={n} {tag}: {digest}")
         manifest["sets"][str(n)] = entry
+
+    # the reference's other SIMD_SET builds (SSE: 4-wide packs, scalar: 1-wide), digests only
+    manifest["simd_variants"] = {}
+    for name, lanes in (("sse", 4), ("scalar", 1)):
+        so = os.path.join(ROOT, "oracle", "_ref", f"libnbody_ref_cpu_{name}.so")
+        if not os.path.exists(so):
+            continue
+        vref = C.CDLL(so)
+        vref.AllocPackArray.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32]
+        vref.PackParticles.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
+        vref.PackedUpdate.argtypes = [C.c_void_p, C.c_float, C.c_uint32, C.c_void_p]
+        vref.FreePackArray.argtypes = [C.c_void_p]
+        saved, ref = ref, vref
+        try:
+            for n in (1024, 333):
+                ic = np.fromfile(os.path.join(HERE, f"ic_{n}.bin"), dtype=np.float32).reshape(-1, 8)
+                part = ic.copy()
+                m = orc.orc_partition(part.ctypes.data, n)
+                for (k, dt) in ((1, 0.01), (10, 0.01)):
+                    digest = sha(ref_steps(part, m, dt, k))
+                    manifest["simd_variants"][f"{name}_{n}_s{k}_dt{dt:g}"] = {"lanes": lanes, "n": n, "n_steps": k, "dt": dt, "sha256": digest}
+                    print(f"{name} N={n} s{k}: {digest}")
+        finally:
+            ref = saved
 
     e = manifest["sets"]["4096"]
     checks = {

@@ -39,6 +39,8 @@ def lib():
             f = getattr(L, name)
             f.restype = None
             f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32]
+        L.orc_step_lanes.restype = None
+        L.orc_step_lanes.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32]
         L.orc_acc_f64.restype = None
         L.orc_acc_f64.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_acc_f64_subset.restype = None
@@ -74,6 +76,13 @@ def step(a, mass_len, dt, n, kind="avx_order"):
     """n steps on a copy of partitioned particles; kind in avx_order|avx|seq|f64."""
     out = _check(np.ascontiguousarray(a, dtype=np.float32)).copy()
     getattr(lib(), "orc_step_" + kind)(out.ctypes.data, out.shape[0], mass_len, dt, n)
+    return out
+
+
+def step_lanes(a, mass_len, dt, n, lanes):
+    """n steps in the summation order of the reference build with `lanes`-wide packs (8 AVX, 4 SSE, 1 scalar)."""
+    out = _check(np.ascontiguousarray(a, dtype=np.float32)).copy()
+    lib().orc_step_lanes(out.ctypes.data, out.shape[0], mass_len, dt, n, lanes)
     return out
 
 

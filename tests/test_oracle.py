@@ -109,3 +109,16 @@ def test_thread_count_independent(golden):
     assert used == 1 and sec > 0 and np.isfinite(chk)
     b = ob.step(part, m, 0.01, 3, kind="avx")
     assert a.tobytes() == b.tobytes()
+
+
+def test_sse_and_scalar_builds_of_the_reference(manifest, golden):
+    # digests taken from the reference's sim_cpu.c compiled with -DUSE_SSE and with no SIMD define
+    v = manifest["simd_variants"]
+    assert {e["lanes"] for e in v.values()} == {1, 4}
+    for tag, e in v.items():
+        part, m = ob.partition(golden(f"ic_{e['n']}.bin"))
+        got = ob.step_lanes(part, m, e["dt"], e["n_steps"], e["lanes"])
+        assert ob.sha256(got) == e["sha256"], tag
+    part, m = ob.partition(golden("ic_333.bin"))
+    assert ob.step_lanes(part, m, 0.01, 2, 8).tobytes() == ob.step(part, m, 0.01, 2).tobytes()
+    assert ob.step_lanes(part, m, 0.01, 2, 1).tobytes() == ob.step(part, m, 0.01, 2, kind="seq").tobytes()
