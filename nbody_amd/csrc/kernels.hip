@@ -62,7 +62,13 @@ __device__ __forceinline__ void interact(Receivers<K> &R, float sx, float sy, fl
         const float dy = sy - R.y[k];
         float d2 = __builtin_fmaf(dx, dx, R.r[k]);  // softening: + radius of the RECEIVER, not squared
         d2 = __builtin_fmaf(dy, dy, d2);
-        const float inv = __builtin_amdgcn_rsqf(d2);  // v_rsq_f32, 1 ulp
+        // v_rsq_f32 (1 ulp) issued at raised wave priority: on gfx950 a transcendental sprinkled between the
+        // plain VALU instructions of the other waves of its SIMD costs ~16 cycles instead of 8; with the
+        // priority raised for just that instruction the penalty all but disappears
+        // (profiles/r01_ubench5_setprio_rsq.txt: 195 -> 143 cycles per 32 fma + 8 rsq; in this kernel +3 %,
+        // profiles/r01_sweep6_setprio_kernel.txt).
+        float inv;
+        asm("s_setprio 3\n\tv_rsq_f32 %0, %1\n\ts_setprio 0" : "=v"(inv) : "v"(d2));
         // G*m / dist^3 as three plain v_mul_f32, pinned with asm: left alone, hipcc's SLP pass pairs them into
         // two v_pk_mul_f32 (one of them computing f twice) plus a v_mov of G*m into a VGPR, which is slower
         // (profiles/r01_sweep5_asm_mul_hazard_fixed.txt: +1.7 % SMEM, +11 % LDS).  gfx950 needs one wait state

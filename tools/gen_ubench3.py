@@ -33,8 +33,19 @@ def head(u, k, j, packed):
     return a + [f"v_fma_f32 {Q(j)}, {DX(j)}, {DX(j)}, {R(k)}", f"v_fmac_f32 {Q(j)}, {DY(j)}, {DY(j)}"]
 
 
+PRIO = False
+
+
 def rsq(j):
+    if PRIO:
+        return ["s_setprio 3", f"v_rsq_f32 {Q(j)}, {Q(j)}", "s_setprio 0"]
     return [f"v_rsq_f32 {Q(j)}, {Q(j)}"]
+
+
+def rsq_group(js):
+    if PRIO:
+        return ["s_setprio 3"] + [f"v_rsq_f32 {Q(j)}, {Q(j)}" for j in js] + ["s_setprio 0"]
+    return [f"v_rsq_f32 {Q(j)}, {Q(j)}" for j in js]
 
 
 def tail(u, k, j, packed):
@@ -65,13 +76,13 @@ def body(order, packed):
     elif order == "phase4":      # per source: heads of 4 receivers interleaved, 4 rsq, tails interleaved
         for u in range(8):
             ins += interleave([head(u, k, k, packed) for k in range(4)])
-            ins += [x for k in range(4) for x in rsq(k)]
+            ins += rsq_group(range(4))
             ins += interleave([tail(u, k, k, packed) for k in range(4)])
     elif order == "phase8":      # per 2 sources: 8 heads, 8 rsq, 8 tails
         for u in range(0, 8, 2):
             sl = [(u + d, k, 4 * d + k) for d in range(2) for k in range(4)]
             ins += interleave([head(uu, k, j, packed) for (uu, k, j) in sl])
-            ins += [x for (_, _, j) in sl for x in rsq(j)]
+            ins += rsq_group([j for (_, _, j) in sl])
             ins += interleave([tail(uu, k, j, packed) for (uu, k, j) in sl])
     elif order == "pipe4":       # rotated: head(u+1) | rsq(u+1) | tail(u); slots alternate between two banks of 4
         def H(u): return interleave([head(u, k, 4 * (u & 1) + k, packed) for k in range(4)])
@@ -106,19 +117,20 @@ def body(order, packed):
     return ins
 
 
-VARIANTS = [(o, p) for o in ("serial", "phase4", "phase8", "pipe4", "pipe4b", "mix") for p in (False, True)]
+VARIANTS = [(o, True, pr) for o in ("serial", "phase4", "phase8", "mix") for pr in (False, True)]
 CLOBBER = ", ".join(f'"v{i}"' for i in range(52)) + ", " + ", ".join(f'"s{i}"' for i in range(16, 40))
 
 src = ['// GENERATED by tools/gen_ubench3.py -- candidate inner bodies of the step kernel (see that file).',
        '#include <hip/hip_runtime.h>', '#include <cstdio>', '#include <cstdlib>',
        '#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\\n", __FILE__, __LINE__, hipGetErrorString(e_)); abort(); } } while (0)',
        '']
-for vi, (o, p) in enumerate(VARIANTS):
+for vi, (o, p, pr) in enumerate(VARIANTS):
+    PRIO = pr
     ins = body(o, p)
     init = [f"v_cvt_f32_u32 v{i}, v{i}" for i in range(0)]  # nothing
     setup = [f"v_mov_b32 v{i}, {1.0 + 0.37 * i:.3f}" for i in range(12)] + [f"v_mov_b32 v{i}, 0" for i in range(12, 20)]
     setup += [f"s_mov_b32 s{16+i}, {2.0 + 0.11 * i:.3f}" for i in range(24)]
-    src.append(f'// {o} {"packed" if p else "plain"}: {len(ins)} VALU instructions per 32 interactions')
+    src.append(f'// {o} {"prio" if pr else "noprio"}: {len(ins)} instructions per 32 interactions')
     src.append(f'__global__ __launch_bounds__(256) void body{vi}(float *out, int iters) {{')
     src.append('    asm volatile("' + '\\n\\t'.join(setup) + f'" ::: {CLOBBER});')
     src.append('    for (int it = 0; it < iters; it++) {')
@@ -128,7 +140,7 @@ for vi, (o, p) in enumerate(VARIANTS):
     src.append('    if (s == 12345.678f) out[0] = s;')
     src.append('}')
     src.append('')
-names = ", ".join(f'"{o} {"packed" if p else "plain"}"' for (o, p) in VARIANTS)
+names = ", ".join(f'"{o} {"prio" if pr else "noprio"}"' for (o, p, pr) in VARIANTS)
 fns = ", ".join(f"body{i}" for i in range(len(VARIANTS)))
 src.append(f'''int main() {{
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
