@@ -117,8 +117,8 @@ def pmc_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=N_PARTICLES, help="particles (default 2^20, the metric's size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
