@@ -75,7 +75,8 @@ __device__ __forceinline__ void interact(Receivers<K> &R, float sx, float sy, fl
         // between a transcendental and a VALU instruction that reads its result; hipcc pads that for its own
         // instructions but cannot see into an asm statement, so the statement carries its own s_nop (without
         // it some lanes read a stale `inv`: the parity tests caught exactly that).  `sg` is wave-uniform in
-        // both variants ("s": the LDS route gets a v_readfirstlane).
+        // both variants ("s": the LDS route gets a v_readfirstlane).  Other placements of the priority window
+        // or fusing both statements measured no better (profiles/r01_sweep7_priority_modes.txt).
         float inv2, f;
         asm("s_nop 0\n\tv_mul_f32 %1, %3, %3\n\tv_mul_f32 %0, %2, %3\n\tv_mul_f32 %0, %0, %1"
             : "=&v"(f), "=&v"(inv2)
