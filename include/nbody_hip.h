@@ -133,12 +133,13 @@ SimPipeline *CreateSimPipelineSharded(WorldData data, int rank, int nranks, cons
 
 /* The shard arithmetic, pure host code (usable without a GPU). */
 typedef struct NbShardPlan {
-    uint32_t mass_chunk;   /* Mc: massive slots per rank (uniform, padded)             */
-    uint32_t zero_chunk;   /* Zc: massless slots per rank (uniform, padded)            */
+    uint32_t mass_chunk;   /* Mc: massive slots per rank = all-gather count (uniform)   */
+    uint32_t zero_chunk;   /* Zc: massless slots allocated per rank (uniform, >= any)   */
     uint32_t mass_begin;   /* first global massive index owned: rank * Mc, clamped      */
     uint32_t mass_count;   /* owned massive particles (<= Mc)                           */
     uint32_t zero_begin;   /* first global massless index owned (>= mass_len), clamped  */
-    uint32_t zero_count;   /* owned massless particles (<= Zc)                          */
+    uint32_t zero_count;   /* owned massless particles (<= Zc), dealt to level the      */
+                           /* per-rank totals mass_count + zero_count                   */
     uint32_t src_padded;   /* nranks * Mc: length of the gathered source array          */
 } NbShardPlan;
 

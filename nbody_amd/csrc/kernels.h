@@ -31,9 +31,14 @@ struct StepParams {
     float2 *vel;
     float2 *acc;
     const float *radius;
-    uint32_t n_recv;
-    // new positions of receivers [0, n_mirror) are also written here (the shard's slice of the
-    // next gathered source array); n_mirror == 0 disables it
+    uint32_t n_recv;      // receivers this launch computes (logical indices 0 .. n_recv)
+    // logical receiver i lives in slot i + (i >= recv_split ? recv_gap : 0): a shard's massive slice is padded
+    // to the uniform all-gather chunk, and the pad slots must not cost workgroups (one extra workgroup on a
+    // 2-round grid is +50 %, profiles/r01_shard_overhead_before_fix.txt).  Unsharded: recv_split = n_recv.
+    uint32_t recv_split;
+    uint32_t recv_gap;
+    // new positions of the receivers in slots [0, n_mirror) are also written here (the shard's slice of
+    // the next gathered source array); n_mirror == 0 disables it
     float2 *mirror;
     uint32_t n_mirror;
     float dt;

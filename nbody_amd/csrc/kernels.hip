@@ -96,6 +96,11 @@ __device__ __forceinline__ void interact8(Receivers<K> &R, const VP &P, const VG
     for (int u = 0; u < 8; u++) interact<K>(R, P[2 * u], P[2 * u + 1], G[u]);
 }
 
+// Slot of logical receiver i (see StepParams::recv_split).
+__device__ __forceinline__ uint32_t receiver_slot(const StepParams &p, uint32_t i) {
+    return i + (i >= p.recv_split ? p.recv_gap : 0u);
+}
+
 // Map a position v of the concatenated source ranges to an index of src_pos/src_gm.
 __device__ __forceinline__ uint32_t source_index(const StepParams &p, uint32_t v, uint32_t n0) {
     return v < n0 ? p.src_begin[0] + v : p.src_begin[1] + (v - n0);
@@ -117,6 +122,7 @@ __global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
     for (int k = 0; k < K; k++) {
         uint32_t i = recv_base + k * WAVE + lane;
         i = i < p.n_recv ? i : p.n_recv - 1;  // tail lanes redo the last receiver; their stores are masked
+        i = receiver_slot(p, i);
         const float2 q = p.pos_in[i];
         R.x[k] = q.x;
         R.y[k] = q.y;
@@ -211,8 +217,9 @@ __global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
     }
 
     // ---- combine the W slices in wave order, integrate, store -------------------------------------------
-    auto finish = [&](uint32_t i, float sx, float sy) {
-        if (i >= p.n_recv) return;
+    auto finish = [&](uint32_t logical, float sx, float sy) {
+        if (logical >= p.n_recv) return;
+        const uint32_t i = receiver_slot(p, logical);
         float2 a = make_float2(sx, sy);
         if (p.flags & STEP_ACC_IN) {
             const float2 a0 = p.acc[i];
@@ -326,10 +333,22 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, int compute_units) {
     LaunchShape s = want;
     if (compute_units <= 0) compute_units = 256;
     if (s.k == 0) {
-        // two receivers per lane once that still leaves two workgroups per CU; four cost occupancy (71 VGPRs)
-        // and one is 8 % slower at large N (profiles/r01_sweep4_shapes_by_n.txt)
-        const uint32_t groups2 = (n_recv + WAVE * 2 - 1) / (WAVE * 2);
-        s.k = groups2 >= 2u * (uint32_t)compute_units ? 2 : 1;
+        // Workgroups all take the same time, so a launch costs rounds * work-per-workgroup, where a round is
+        // the chip's resident capacity (two 1024-thread workgroups per CU at <= 64 VGPRs): pick the K in {2, 1}
+        // with the cheaper product, K = 2 on ties (it is 8 % faster per interaction at large N, while K = 4
+        // needs 71 VGPRs and loses occupancy; profiles/r01_sweep4_shapes_by_n.txt).  One workgroup past a
+        // multiple of the capacity costs a whole round: 1025 workgroups on 512 slots run 1.5x as long as 1024.
+        const uint32_t capacity = 2u * (uint32_t)compute_units;
+        uint32_t best_cost = 0;
+        for (int k = 2; k >= 1; k--) {
+            const uint32_t groups = (n_recv + WAVE * k - 1) / (WAVE * k);
+            const uint32_t rounds = (groups + capacity - 1) / capacity;
+            const uint32_t cost = rounds * (uint32_t)k;
+            if (s.k == 0 || cost < best_cost) {
+                s.k = k;
+                best_cost = cost;
+            }
+        }
     }
     if (s.w == 0) {
         // 16 source slices per workgroup: fastest at every size measured, and the shortest fp32 sums

@@ -177,7 +177,8 @@ struct SimPipeline {
     struct LocalGroup *group = nullptr;  // test transport: all ranks are pipelines of this process (no RCCL)
 
     bool on_device = false;  // buffers exist and hold data
-    uint32_t slots = 0;      // receiver slots on this device
+    uint32_t slots = 0;      // receiver slots on this device (allocation; includes a shard's pad slots)
+    uint32_t n_real = 0;     // receivers actually computed (== slots when unsharded)
     uint32_t n_src = 0;      // sources every receiver sees (mass_len, or the padded gathered length)
 
     // SoA streams (DESIGN.md "Layout in HBM")
@@ -263,8 +264,10 @@ void materialize(SimPipeline *s) {
     const uint32_t N = s->data.total_len, M = s->data.mass_len;
     if (!s->sharded) {
         s->slots = N;
+        s->n_real = N;
         s->n_src = M;
     } else {
+        s->n_real = s->plan.mass_count + s->plan.zero_count;
         if (!s->group) ASSERT_HIP(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking), "comm stream");
         s->slots = s->plan.mass_chunk + s->plan.zero_chunk;
         s->n_src = s->plan.src_padded;
@@ -290,10 +293,10 @@ void materialize(SimPipeline *s) {
 
 nb::LaunchShape resolve_shape(SimPipeline *s) {
     nb::LaunchShape want = {s->want_k, s->want_w, s->want_variant};
-    nb::LaunchShape sh = nb::choose_shape(want, s->slots, g_dev.compute_units);
+    nb::LaunchShape sh = nb::choose_shape(want, s->n_real, g_dev.compute_units);
     NB_ASSERT(nb::step_kernel_fn(sh) != nullptr, "no step kernel for k=%d w=%d variant=%d", sh.k, sh.w, sh.variant);
     s->last_shape = sh;
-    s->last_groups = nb::step_grid(sh, s->slots).x;
+    s->last_groups = nb::step_grid(sh, s->n_real).x;
     return sh;
 }
 
@@ -311,10 +314,15 @@ nb::StepParams whole_step(const SimPipeline *s, int in, float dt) {
     p.vel = s->vel;
     p.acc = s->acc;
     p.radius = s->radius;
-    p.n_recv = s->slots;
+    p.n_recv = s->n_real;
+    p.recv_split = s->n_real;
+    p.recv_gap = 0;
     if (s->sharded) {
+        // slots [0, mass_count) massive, [mass_count, Mc) pads (never computed), [Mc, Mc + zero_count) massless
+        p.recv_split = s->plan.mass_count;
+        p.recv_gap = s->plan.mass_chunk - s->plan.mass_count;
         p.mirror = s->src_pos[in ^ 1] + (size_t)s->rank * s->plan.mass_chunk;
-        p.n_mirror = s->plan.mass_chunk;
+        p.n_mirror = s->plan.mass_count;
     }
     p.dt = dt;
     p.flags = 0;
@@ -324,8 +332,9 @@ nb::StepParams whole_step(const SimPipeline *s, int in, float dt) {
 void launch_step(SimPipeline *s, nb::LaunchShape sh, const nb::StepParams &p, hipStream_t st) {
     nb::StepParams copy = p;
     void *args[] = {&copy};
-    ASSERT_HIP(hipLaunchKernel(nb::step_kernel_fn(sh), nb::step_grid(sh, s->slots), nb::step_block(sh), args, 0, st),
-               "step kernel launch (k=%d w=%d variant=%d, %u receivers)", sh.k, sh.w, sh.variant, s->slots);
+    if (s->n_real == 0) return;  // a rank without receivers still takes part in the gathers
+    ASSERT_HIP(hipLaunchKernel(nb::step_kernel_fn(sh), nb::step_grid(sh, s->n_real), nb::step_block(sh), args, 0, st),
+               "step kernel launch (k=%d w=%d variant=%d, %u receivers)", sh.k, sh.w, sh.variant, s->n_real);
 }
 
 // ---- single-device chains ------------------------------------------------------------------------------------
@@ -351,7 +360,7 @@ StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchS
             hipKernelNodeParams kp;
             memset(&kp, 0, sizeof kp);
             kp.func = const_cast<void *>(nb::step_kernel_fn(sh));
-            kp.gridDim = nb::step_grid(sh, s->slots);
+            kp.gridDim = nb::step_grid(sh, s->n_real);
             kp.blockDim = nb::step_block(sh);
             kp.sharedMemBytes = 0;
             kp.kernelParams = args;
@@ -372,7 +381,7 @@ StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchS
             hipKernelNodeParams kp;
             memset(&kp, 0, sizeof kp);
             kp.func = const_cast<void *>(nb::step_kernel_fn(sh));
-            kp.gridDim = nb::step_grid(sh, s->slots);
+            kp.gridDim = nb::step_grid(sh, s->n_real);
             kp.blockDim = nb::step_block(sh);
             kp.kernelParams = args;
             ASSERT_HIP(hipGraphExecKernelNodeSetParams(g->exec, g->nodes[i], &kp), "hipGraphExecKernelNodeSetParams");
@@ -511,20 +520,59 @@ NbShardPlan nb_hip_shard_plan(uint32_t total_len, uint32_t mass_len, int rank, i
     NB_ASSERT(nranks >= 1 && rank >= 0 && rank < nranks, "rank %d of %d", rank, nranks);
     NB_ASSERT(mass_len <= total_len, "mass_len %u > total_len %u", mass_len, total_len);
     NbShardPlan p;
-    const uint32_t P = (uint32_t)nranks, r = (uint32_t)rank;
+    const uint32_t P = (uint32_t)nranks;
     const uint32_t Z = total_len - mass_len;
-    // uniform, wave-aligned chunks: every rank contributes the same count to the all-gather
-    p.mass_chunk = round_up((mass_len + P - 1) / P, 64);
-    p.zero_chunk = round_up((Z + P - 1) / P, 64);
-    if (mass_len == 0) p.mass_chunk = 0;
-    if (Z == 0) p.zero_chunk = 0;
-    const uint64_t mb = (uint64_t)r * p.mass_chunk;
+    // Massive slices: uniform, wave-aligned chunks, so every rank contributes the same count to the all-gather
+    // and gathered index == global massive index.  The last ranks may own fewer (or no) real sources.
+    const uint32_t Mc = mass_len ? round_up((mass_len + P - 1) / P, 64) : 0;
+    auto mass_of = [&](uint32_t q) -> uint32_t {
+        const uint64_t b = (uint64_t)q * Mc;
+        return b < mass_len ? (mass_len - (uint32_t)b < Mc ? mass_len - (uint32_t)b : Mc) : 0;
+    };
+    // Massless slices: every receiver costs the same (all sources), so they are dealt out to level the
+    // per-rank totals ("water filling"): find the lowest level L with sum_q max(0, L - mass_q) >= Z, give
+    // rank q max(0, L - mass_q), and take the surplus back one by one from the highest ranks that got any.
+    // An equal total per rank keeps the workgroup count on a round boundary (see choose_shape).
+    uint64_t lo = 0, hi = (uint64_t)total_len + 1;
+    while (lo < hi) {
+        const uint64_t L = (lo + hi) / 2;
+        uint64_t got = 0;
+        for (uint32_t q = 0; q < P; q++) got += L > mass_of(q) ? L - mass_of(q) : 0;
+        if (got >= Z)
+            hi = L;
+        else
+            lo = L + 1;
+    }
+    const uint64_t level = lo;
+    uint64_t surplus = 0;
+    for (uint32_t q = 0; q < P; q++) surplus += level > mass_of(q) ? level - mass_of(q) : 0;
+    surplus -= Z;
+    uint32_t zero_begin = mass_len, zero_max = 0, my_zero_begin = mass_len, my_zero = 0;
+    // surplus < number of ranks at the level: rank q gives one back if it is among the last `surplus` takers
+    uint32_t takers = 0;
+    for (uint32_t q = 0; q < P; q++) takers += level > mass_of(q);
+    uint32_t seen = 0;
+    for (uint32_t q = 0; q < P; q++) {
+        uint32_t z = level > mass_of(q) ? (uint32_t)(level - mass_of(q)) : 0;
+        if (level > mass_of(q)) {
+            if (seen >= takers - (uint32_t)surplus) z -= 1;
+            seen++;
+        }
+        if (q == (uint32_t)rank) {
+            my_zero_begin = zero_begin;
+            my_zero = z;
+        }
+        zero_begin += z;
+        zero_max = z > zero_max ? z : zero_max;
+    }
+    p.mass_chunk = Mc;
+    p.zero_chunk = round_up(zero_max, 64);
+    const uint64_t mb = (uint64_t)rank * Mc;
     p.mass_begin = mb < mass_len ? (uint32_t)mb : mass_len;
-    p.mass_count = mb < mass_len ? (mass_len - p.mass_begin < p.mass_chunk ? mass_len - p.mass_begin : p.mass_chunk) : 0;
-    const uint64_t zb = (uint64_t)r * p.zero_chunk;
-    p.zero_begin = mass_len + (zb < Z ? (uint32_t)zb : Z);
-    p.zero_count = zb < Z ? (Z - (uint32_t)zb < p.zero_chunk ? Z - (uint32_t)zb : p.zero_chunk) : 0;
-    p.src_padded = P * p.mass_chunk;
+    p.mass_count = mass_of((uint32_t)rank);
+    p.zero_begin = my_zero_begin;
+    p.zero_count = my_zero;
+    p.src_padded = P * Mc;
     return p;
 }
 
@@ -598,7 +646,6 @@ void nb_hip_local_group_step(SimPipeline **sims, int nranks, uint32_t n, float d
     for (uint32_t i = 0; i < n; i++)
         for (int r = 0; r < nranks; r++) {
             SimPipeline *s = sims[r];
-            if (s->slots == 0) continue;
             sharded_step(s, resolve_shape(s), dt, g->stream);
         }
     ASSERT_HIP(hipStreamSynchronize(g->stream), "group sync");

@@ -379,6 +379,28 @@ def test_local_shard_group_default_shape_within_tolerance(golden, P, overlap):
     assert np.linalg.norm(ten[:, 0:2] - want[:, 0:2]) / np.linalg.norm(want[:, 0:2]) <= 1e-6
 
 
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_local_shard_group_config4_shape(overlap):
+    """BASELINE config 4/5 in miniature: 8 shards of a 65536-particle universe, spot-checked against float64."""
+    n, P = 65536, 8
+    ic = nb.make_galaxies(n, 2, seed=11037)
+    w = nb.World(ic)
+    part = w.particles()
+    w.close()
+    m = int((part[:, 6] > 0).sum())
+    g = nb.LocalShardGroup(n, m, P, overlap=overlap)
+    g.set_data(part)
+    g.step(1, 0.01)
+    got = g.get_data(3)
+    g.close()
+    idx = np.unique(np.random.default_rng(8).integers(0, n, 800)).astype(np.uint32)
+    acc64, mag = ob.acc_f64_subset(part, m, idx)
+    assert np.all(np.abs(got[idx, 4:6].astype(np.float64) - acc64) <= acc_bound(acc64, mag))
+    v = part[:, 2:4] + got[:, 4:6] * np.float32(0.01)
+    assert np.array_equal(got[:, 2:4], v) and np.array_equal(got[:, 0:2], part[:, 0:2] + v * np.float32(0.01))
+    assert np.array_equal(got[:, 6:8], part[:, 6:8])
+
+
 def test_local_shard_group_ragged(golden):
     part, m = synth(1000, 0.013, seed=4)      # 13 sources over 4 ranks: some ranks own no source
     g = nb.LocalShardGroup(1000, m, 4)
