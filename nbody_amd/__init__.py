@@ -80,10 +80,21 @@ def _bind(lib, api):
     return lib
 
 
+def _build_if_missing(path):
+    """A missing library is built once, loudly; there is no other implementation to fall back to."""
+    if os.path.exists(path) or os.environ.get("NBODY_HIP_SO"):
+        return
+    import sys
+    from . import build as _build
+    print(f"[nbody_amd] {path} missing: building the product libraries (hipcc, gfx950)", file=sys.stderr, flush=True)
+    _build.build_product()
+
+
 def hip_lib():
-    """libnbody_hip.so, loaded once.  Raises OSError when it has not been built."""
+    """libnbody_hip.so, loaded once.  Raises OSError when it cannot be built or loaded."""
     global _hip
     if _hip is None:
+        _build_if_missing(HIP_SO)
         if not os.path.exists(HIP_SO):
             raise OSError(f"{HIP_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
         _hip = _bind(C.CDLL(HIP_SO, mode=C.RTLD_GLOBAL), HIP_API)
@@ -95,6 +106,7 @@ def nbody_lib():
     global _nbody
     if _nbody is None:
         hip_lib()
+        _build_if_missing(NBODY_SO)
         if not os.path.exists(NBODY_SO):
             raise OSError(f"{NBODY_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
         _nbody = _bind(C.CDLL(NBODY_SO, mode=C.RTLD_GLOBAL), NBODY_API)

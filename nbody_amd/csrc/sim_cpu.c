@@ -80,8 +80,12 @@ void CpuSimStep(CpuSim *sim, Particle *arr, uint32_t total_len, uint32_t mass_le
     NB_CHECK(padded <= sim->capacity, "snapshot holds %u sources, asked for %u", sim->capacity, mass_len);
     float *sx = sim->sx, *sy = sim->sy, *sm = sim->sm;
 
+    /* below ~2*10^5 interactions a parallel region costs more than it saves (and far more on a box whose
+     * OpenMP default oversubscribes its CPU quota); results do not depend on the thread count */
+    const int go_parallel = (double)total_len * (double)(mass_len ? mass_len : 1) >= 2.0e5;
+
     /* snapshot = Jacobi semantics: every receiver sees the pre-step sources */
-#pragma omp parallel for schedule(static, 1024)
+#pragma omp parallel for schedule(static, 1024) if (go_parallel)
     for (uint32_t j = 0; j < padded; j++) {
         const int live = j < mass_len;
         sx[j] = live ? arr[j].pos.x : 0.0f;
@@ -91,7 +95,7 @@ void CpuSimStep(CpuSim *sim, Particle *arr, uint32_t total_len, uint32_t mass_le
 
     const __m256 g = _mm256_set1_ps(NB_G);
     const uint32_t pairs = total_len / 2u;
-#pragma omp parallel for schedule(static, 16)
+#pragma omp parallel for schedule(static, 16) if (go_parallel)
     for (uint32_t q = 0; q < pairs; q++) {
         Particle *a = &arr[2u * q], *b = a + 1;
         const __m256 xa = _mm256_set1_ps(a->pos.x), ya = _mm256_set1_ps(a->pos.y), ra = _mm256_set1_ps(a->radius);
