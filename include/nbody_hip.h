@@ -105,6 +105,8 @@ double nb_hip_last_step_ms(SimPipeline *sim, uint32_t *launches);
  *   "variant"   0 = wave-private LDS tiles, 1 = scalar-cache (SMEM) source broadcast (default: measured faster)
  *   "k"         receivers per lane: 0 = auto, else 1, 2 or 4
  *   "w"         waves (source slices) per workgroup: 0 = auto, else 1, 2, 4, 8 or 16
+ *   "split"     workgroups per receiver tile, each over 1/split of the sources (a second small kernel adds
+ *               the parts and integrates): 0 = auto (fills the chip / lands on a round boundary), else 1..16
  *   "graph"     1 = run step chains as hipGraphs (default), 0 = plain stream launches
  *   "overlap"   sharded pipelines: 1 = split each step into own-shard / remote-shard kernels
  *               with the all-gather in between on a second stream, 0 = gather then one kernel
@@ -112,8 +114,8 @@ double nb_hip_last_step_ms(SimPipeline *sim, uint32_t *launches);
  */
 int nb_hip_configure(SimPipeline *sim, const char *key, int value);
 
-/* What the last step launch actually used (after "auto"): fills k, w, variant, workgroups. */
-void nb_hip_launch_shape(const SimPipeline *sim, int *k, int *w, int *variant, uint32_t *workgroups);
+/* What the last step launch actually used (after "auto"): fills k, w, variant, split, workgroups. */
+void nb_hip_launch_shape(const SimPipeline *sim, int *k, int *w, int *variant, int *split, uint32_t *workgroups);
 
 /* -- sharded (multi-GPU) pipeline: one process per GPU, N/P receivers each -- */
 

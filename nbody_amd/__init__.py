@@ -49,7 +49,7 @@ HIP_API = {
     "nb_hip_last_step_ms": (C.c_double, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "nb_hip_configure": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "nb_hip_launch_shape": (None, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
-                                   C.POINTER(C.c_uint32)]),
+                                   C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "nb_hip_comm_unique_id": (None, [C.c_void_p]),
     "CreateSimPipelineSharded": (C.c_void_p, [WorldData, C.c_int, C.c_int, C.c_void_p]),
     "nb_hip_shard_plan": (NbShardPlan, [C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
@@ -200,9 +200,10 @@ class SimPipeline:
             hip_lib().nb_hip_configure(self._h, k.encode(), int(v))
 
     def launch_shape(self):
-        k, w, v, g = C.c_int(), C.c_int(), C.c_int(), C.c_uint32()
-        hip_lib().nb_hip_launch_shape(self._h, C.byref(k), C.byref(w), C.byref(v), C.byref(g))
-        return {"k": k.value, "w": w.value, "variant": "smem" if v.value else "lds", "workgroups": g.value}
+        k, w, v, sp, g = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_uint32()
+        hip_lib().nb_hip_launch_shape(self._h, C.byref(k), C.byref(w), C.byref(v), C.byref(sp), C.byref(g))
+        return {"k": k.value, "w": w.value, "variant": "smem" if v.value else "lds", "split": sp.value,
+                "workgroups": g.value}
 
 
 class LocalShardGroup:

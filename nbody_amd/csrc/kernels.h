@@ -43,21 +43,34 @@ struct StepParams {
     uint32_t n_mirror;
     float dt;
     uint32_t flags;
+    // source split: gridDim.y = split workgroups share one receiver tile, each over 1/split of the source
+    // chunks; with split > 1 the step kernel only stores its sums to parts[part][receiver] and finish_kernel
+    // adds the parts in order and integrates.  Fills the chip when there are few receiver tiles and lands the
+    // workgroup count near a round boundary (see choose_shape).
+    float2 *parts;
+    uint32_t split;
 };
 
 struct LaunchShape {
     int k;        // receivers per lane: 1, 2, 4
     int w;        // waves per workgroup = source slices: 1, 2, 4, 8, 16
     int variant;  // VARIANT_*
+    int split;    // workgroups per receiver tile (source parts): 1 .. MAX_SPLIT
 };
 
-// Resolve "auto" (0) entries of `want` for a launch over n_recv receivers.
-LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, int compute_units);
+constexpr int MAX_SPLIT = 16;
+
+// Resolve "auto" (0) entries of `want` for a launch over n_recv receivers and n_src sources.
+LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int compute_units);
 
 // Kernel entry point and grid for a shape; used both for direct launches and for graph nodes.
 const void *step_kernel_fn(LaunchShape s);
 dim3 step_grid(LaunchShape s, uint32_t n_recv);
 dim3 step_block(LaunchShape s);
+// second kernel of a split step (split > 1): adds the parts and finishes like the step kernel's epilogue
+const void *finish_kernel_fn();
+dim3 finish_grid(uint32_t n_recv);
+dim3 finish_block();
 
 // AoS <-> SoA converters (reference Particle layout, include/nbody.h).
 // split: aos[first .. first+count) -> soa slots [slot0 .. slot0+count); gm = NB_G * mass

@@ -106,6 +106,43 @@ __device__ __forceinline__ uint32_t source_index(const StepParams &p, uint32_t v
     return v < n0 ? p.src_begin[0] + v : p.src_begin[1] + (v - n0);
 }
 
+// Epilogue of one receiver: optional carried-in sum, store acc, then the reference's integrator.
+__device__ __forceinline__ void finish_receiver(const StepParams &p, uint32_t logical, float sx, float sy) {
+    if (logical >= p.n_recv) return;
+    const uint32_t i = receiver_slot(p, logical);
+    float2 a = make_float2(sx, sy);
+    if (p.flags & STEP_ACC_IN) {
+        const float2 a0 = p.acc[i];
+        a.x = __fadd_rn(a0.x, a.x);
+        a.y = __fadd_rn(a0.y, a.y);
+    }
+    p.acc[i] = a;
+    if (p.flags & STEP_NO_FINALIZE) return;
+    // semi-implicit Euler with the reference's roundings: vel += acc*dt; pos += vel*dt
+    float2 v = p.vel[i];
+    v.x = __fadd_rn(v.x, __fmul_rn(a.x, p.dt));
+    v.y = __fadd_rn(v.y, __fmul_rn(a.y, p.dt));
+    float2 q = p.pos_in[i];
+    q.x = __fadd_rn(q.x, __fmul_rn(v.x, p.dt));
+    q.y = __fadd_rn(q.y, __fmul_rn(v.y, p.dt));
+    p.vel[i] = v;
+    p.pos_out[i] = q;
+    if (i < p.n_mirror) p.mirror[i] = q;
+}
+
+// Second kernel of a split step: one thread per receiver adds the parts in part order and finishes.
+__global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
+    const uint32_t logical = blockIdx.x * blockDim.x + threadIdx.x;
+    if (logical >= p.n_recv) return;
+    float sx = 0.0f, sy = 0.0f;
+    for (uint32_t s = 0; s < p.split; s++) {
+        const float2 t = p.parts[(size_t)s * p.n_recv + logical];
+        sx = __fadd_rn(sx, t.x);
+        sy = __fadd_rn(sy, t.y);
+    }
+    finish_receiver(p, logical, sx, sy);
+}
+
 template <int K, int W, int VARIANT>
 __global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
     const uint32_t tid = threadIdx.x;
@@ -135,9 +172,13 @@ __global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
     const uint32_t n1 = p.src_end[1] - p.src_begin[1];
     const uint32_t total = n0 + n1;
     const uint32_t nchunks = (total + CHUNK - 1) / CHUNK;
-    const uint32_t per_wave = (nchunks + W - 1) / W;
-    const uint32_t c_lo = min(wid * per_wave, nchunks);
-    const uint32_t c_hi = min(c_lo + per_wave, nchunks);
+    // this workgroup's part of the chunks (all of them unless the step is split), then this wave's slice of it
+    const uint32_t per_part = (nchunks + p.split - 1) / p.split;
+    const uint32_t part_lo = min(blockIdx.y * per_part, nchunks);
+    const uint32_t part_hi = min(part_lo + per_part, nchunks);
+    const uint32_t per_wave = (part_hi - part_lo + W - 1) / W;
+    const uint32_t c_lo = min(part_lo + wid * per_wave, part_hi);
+    const uint32_t c_hi = min(c_lo + per_wave, part_hi);
 
     if constexpr (VARIANT == VARIANT_LDS) {
         float(*T)[3][CHUNK] = tile[wid];
@@ -218,26 +259,11 @@ __global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
 
     // ---- combine the W slices in wave order, integrate, store -------------------------------------------
     auto finish = [&](uint32_t logical, float sx, float sy) {
-        if (logical >= p.n_recv) return;
-        const uint32_t i = receiver_slot(p, logical);
-        float2 a = make_float2(sx, sy);
-        if (p.flags & STEP_ACC_IN) {
-            const float2 a0 = p.acc[i];
-            a.x = __fadd_rn(a0.x, a.x);
-            a.y = __fadd_rn(a0.y, a.y);
+        if (p.split > 1) {
+            if (logical < p.n_recv) p.parts[(size_t)blockIdx.y * p.n_recv + logical] = make_float2(sx, sy);
+        } else {
+            finish_receiver(p, logical, sx, sy);
         }
-        p.acc[i] = a;
-        if (p.flags & STEP_NO_FINALIZE) return;
-        // semi-implicit Euler with the reference's roundings: vel += acc*dt; pos += vel*dt
-        float2 v = p.vel[i];
-        v.x = __fadd_rn(v.x, __fmul_rn(a.x, p.dt));
-        v.y = __fadd_rn(v.y, __fmul_rn(a.y, p.dt));
-        float2 q = p.pos_in[i];
-        q.x = __fadd_rn(q.x, __fmul_rn(v.x, p.dt));
-        q.y = __fadd_rn(q.y, __fmul_rn(v.y, p.dt));
-        p.vel[i] = v;
-        p.pos_out[i] = q;
-        if (i < p.n_mirror) p.mirror[i] = q;
     };
 
     if constexpr (W == 1) {
@@ -329,39 +355,61 @@ const void *pick(int k, int w) {
 
 }  // namespace
 
-LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, int compute_units) {
-    LaunchShape s = want;
+LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int compute_units) {
+    // Workgroups of one launch all take the same time, so a launch costs
+    //     rounds * (work per workgroup),   rounds = ceil(workgroups / resident capacity),
+    // and one workgroup past a round boundary costs a whole round (1025 workgroups on 512 slots run 1.5x as
+    // long as 1024; profiles/r01_shard_overhead_before_fix.txt).  Work per workgroup = K receivers per lane x
+    // the 64-source chunks one wave walks.  Pick the cheapest (K, W, split); ties go to the larger K, larger W,
+    // smaller split (less traffic, shorter fp32 sums, no second kernel).  K = 4 is left out: 71 VGPRs, lower
+    // occupancy, never faster (profiles/r01_sweep4_shapes_by_n.txt).
     if (compute_units <= 0) compute_units = 256;
-    if (s.k == 0) {
-        // Workgroups all take the same time, so a launch costs rounds * work-per-workgroup, where a round is
-        // the chip's resident capacity (two 1024-thread workgroups per CU at <= 64 VGPRs): pick the K in {2, 1}
-        // with the cheaper product, K = 2 on ties (it is 8 % faster per interaction at large N, while K = 4
-        // needs 71 VGPRs and loses occupancy; profiles/r01_sweep4_shapes_by_n.txt).  One workgroup past a
-        // multiple of the capacity costs a whole round: 1025 workgroups on 512 slots run 1.5x as long as 1024.
-        const uint32_t capacity = 2u * (uint32_t)compute_units;
-        uint32_t best_cost = 0;
-        for (int k = 2; k >= 1; k--) {
-            const uint32_t groups = (n_recv + WAVE * k - 1) / (WAVE * k);
-            const uint32_t rounds = (groups + capacity - 1) / capacity;
-            const uint32_t cost = rounds * (uint32_t)k;
-            if (s.k == 0 || cost < best_cost) {
-                s.k = k;
-                best_cost = cost;
+    const uint32_t chunks = (n_src + CHUNK - 1) / CHUNK;
+    LaunchShape best = want;
+    double best_cost = -1.0;
+    for (int k = 2; k >= 1; k--) {
+        if (want.k != 0 && want.k != k) continue;
+        for (int w = 16; w >= 4; w /= 2) {
+            if (want.w != 0 && want.w != w) continue;
+            for (int sp = 1; sp <= MAX_SPLIT; sp++) {
+                if (want.split != 0 && want.split != sp) continue;
+                const uint64_t groups = ((uint64_t)n_recv + WAVE * k - 1) / (WAVE * k) * (uint64_t)sp;
+                const uint64_t capacity = (uint64_t)compute_units * (32 / w);  // 8 waves per SIMD at <= 64 VGPRs
+                const uint64_t rounds = (groups + capacity - 1) / capacity;
+                const uint32_t part_chunks = (chunks + sp - 1) / sp;
+                const uint32_t wave_chunks = (part_chunks + w - 1) / w;
+                // + 1 chunk-equivalent per workgroup round for prologue/epilogue, + a little for the finish kernel
+                double cost = (double)rounds * ((double)k * (wave_chunks ? wave_chunks : 1) + 1.0);
+                if (sp > 1) cost = cost * 1.03 + 2.0 + 0.05 * sp;  // a split has to pay for itself clearly
+                if (w < 16) cost *= 1.01;
+                if (k == 1) cost *= 1.25;  // measured: hipcc serialises the K = 1 body (profiles/r01_sweep_auto_split.txt)
+                if (best_cost < 0.0 || cost < best_cost * 0.999) {
+                    best_cost = cost;
+                    best.k = k;
+                    best.w = w;
+                    best.split = sp;
+                }
             }
         }
     }
-    if (s.w == 0) {
-        // 16 source slices per workgroup: fastest at every size measured, and the shortest fp32 sums
-        s.w = 16;
+    if (best_cost < 0.0) {  // explicit k = 4 or w in {1, 2}: honour the request as given
+        best.k = want.k ? want.k : 2;
+        best.w = want.w ? want.w : 16;
+        best.split = want.split ? want.split : 1;
     }
-    return s;
+    return best;
 }
 
 const void *step_kernel_fn(LaunchShape s) {
     return s.variant == VARIANT_SMEM ? pick<VARIANT_SMEM>(s.k, s.w) : pick<VARIANT_LDS>(s.k, s.w);
 }
 
-dim3 step_grid(LaunchShape s, uint32_t n_recv) { return dim3((n_recv + WAVE * s.k - 1) / (WAVE * s.k)); }
+dim3 step_grid(LaunchShape s, uint32_t n_recv) {
+    return dim3((n_recv + WAVE * s.k - 1) / (WAVE * s.k), s.split > 1 ? s.split : 1);
+}
+const void *finish_kernel_fn() { return reinterpret_cast<const void *>(&finish_kernel); }
+dim3 finish_grid(uint32_t n_recv) { return dim3((n_recv + 255u) / 256u); }
+dim3 finish_block() { return dim3(256); }
 dim3 step_block(LaunchShape s) { return dim3(WAVE * s.w); }
 
 void launch_split(hipStream_t st, const void *aos, uint32_t first, uint32_t count, float2 *pos, float2 *vel, float2 *acc,

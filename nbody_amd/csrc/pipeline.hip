@@ -157,7 +157,7 @@ struct StepGraph {
     std::vector<nb::StepParams> params; // what each node currently holds
     int phase = -1;                     // which pos buffer the chain reads first
     float dt = 0.0f;
-    nb::LaunchShape shape = {0, 0, 0};
+    nb::LaunchShape shape = {0, 0, 0, 0};
 };
 
 }  // namespace
@@ -191,6 +191,8 @@ struct SimPipeline {
     float *src_gm = nullptr;
     void *aos = nullptr;     // device AoS staging for Set/Get (whole world)
     void *aos_shard = nullptr;  // sharded only: this rank's slice, uniform size
+    float2 *parts = nullptr;    // split steps only: [split][n_real] partial sums
+    uint32_t parts_cap = 0;     // float2 elements allocated in parts
     int cur = 0;             // pos[cur] is the latest state
 
     hipStream_t stream = nullptr;
@@ -201,9 +203,9 @@ struct SimPipeline {
     uint32_t timed_launches = 0;
 
     // knobs
-    int want_variant = nb::VARIANT_SMEM, want_k = 0, want_w = 0;  // SMEM measured 7-17 % faster than LDS tiles
+    int want_variant = nb::VARIANT_SMEM, want_k = 0, want_w = 0, want_split = 0;  // SMEM measured 7-17 % faster than LDS tiles
     int use_graph = 1, overlap = 0;
-    nb::LaunchShape last_shape = {0, 0, 0};
+    nb::LaunchShape last_shape = {0, 0, 0, 0};
     uint32_t last_groups = 0;
 
     std::vector<StepGraph> graphs;
@@ -239,6 +241,9 @@ void release_device(SimPipeline *s) {
     dev_free(s->src_gm);
     dev_free(s->aos);
     dev_free(s->aos_shard);
+    dev_free(s->parts);
+    s->parts = nullptr;
+    s->parts_cap = 0;
     ASSERT_HIP(hipEventDestroy(s->ev_begin), "event");
     ASSERT_HIP(hipEventDestroy(s->ev_end), "event");
     ASSERT_HIP(hipEventDestroy(s->ev_local), "event");
@@ -292,11 +297,24 @@ void materialize(SimPipeline *s) {
 }
 
 nb::LaunchShape resolve_shape(SimPipeline *s) {
-    nb::LaunchShape want = {s->want_k, s->want_w, s->want_variant};
-    nb::LaunchShape sh = nb::choose_shape(want, s->n_real, g_dev.compute_units);
+    // the overlapped sharded step chains two launches through acc[]: keep those unsplit
+    const int split = (s->sharded && s->overlap) ? 1 : s->want_split;
+    nb::LaunchShape want = {s->want_k, s->want_w, s->want_variant, split};
+    nb::LaunchShape sh = nb::choose_shape(want, s->n_real, s->n_src, g_dev.compute_units);
     NB_ASSERT(nb::step_kernel_fn(sh) != nullptr, "no step kernel for k=%d w=%d variant=%d", sh.k, sh.w, sh.variant);
+    if (sh.split > 1) {
+        const size_t need = (size_t)sh.split * s->n_real;
+        if (need > s->parts_cap) {
+            ASSERT_HIP(hipStreamSynchronize(s->stream), "sync before growing the parts buffer");
+            dev_free(s->parts);
+            s->parts = dev_alloc<float2>(need);
+            s->parts_cap = (uint32_t)need;
+            for (auto &g : s->graphs) destroy_graph(g);  // cached nodes point at the old buffer
+            s->graphs.clear();
+        }
+    }
     s->last_shape = sh;
-    s->last_groups = nb::step_grid(sh, s->n_real).x;
+    s->last_groups = nb::step_grid(sh, s->n_real).x * nb::step_grid(sh, s->n_real).y;
     return sh;
 }
 
@@ -326,69 +344,84 @@ nb::StepParams whole_step(const SimPipeline *s, int in, float dt) {
     }
     p.dt = dt;
     p.flags = 0;
+    p.parts = nullptr;
+    p.split = 1;
+    return p;
+}
+
+nb::StepParams shaped(const SimPipeline *s, nb::StepParams p, nb::LaunchShape sh) {
+    p.split = sh.split > 1 ? (uint32_t)sh.split : 1u;
+    p.parts = p.split > 1 ? s->parts : nullptr;
     return p;
 }
 
 void launch_step(SimPipeline *s, nb::LaunchShape sh, const nb::StepParams &p, hipStream_t st) {
-    nb::StepParams copy = p;
-    void *args[] = {&copy};
     if (s->n_real == 0) return;  // a rank without receivers still takes part in the gathers
+    nb::StepParams copy = shaped(s, p, sh);
+    void *args[] = {&copy};
     ASSERT_HIP(hipLaunchKernel(nb::step_kernel_fn(sh), nb::step_grid(sh, s->n_real), nb::step_block(sh), args, 0, st),
-               "step kernel launch (k=%d w=%d variant=%d, %u receivers)", sh.k, sh.w, sh.variant, s->n_real);
+               "step kernel launch (k=%d w=%d variant=%d split=%d, %u receivers)", sh.k, sh.w, sh.variant, sh.split,
+               s->n_real);
+    if (copy.split > 1)
+        ASSERT_HIP(hipLaunchKernel(nb::finish_kernel_fn(), nb::finish_grid(s->n_real), nb::finish_block(), args, 0, st),
+                   "finish kernel launch (%u receivers, %u parts)", s->n_real, copy.split);
 }
 
 // ---- single-device chains ------------------------------------------------------------------------------------
 
+void fill_node(hipKernelNodeParams &kp, void **args, const void *fn, dim3 grid, dim3 block) {
+    memset(&kp, 0, sizeof kp);
+    kp.func = const_cast<void *>(fn);
+    kp.gridDim = grid;
+    kp.blockDim = block;
+    kp.sharedMemBytes = 0;
+    kp.kernelParams = args;
+    kp.extra = nullptr;
+}
+
 StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchShape sh) {
     StepGraph *g = nullptr;
     for (auto &c : s->graphs)
-        if (c.n == n && c.shape.k == sh.k && c.shape.w == sh.w && c.shape.variant == sh.variant) g = &c;
-    if (!g) {
+        if (c.n == n && c.shape.k == sh.k && c.shape.w == sh.w && c.shape.variant == sh.variant && c.shape.split == sh.split)
+            g = &c;
+    const uint32_t per_step = sh.split > 1 ? 2 : 1;  // step kernel (+ finish kernel)
+    const bool fresh = g == nullptr;
+    if (fresh) {
         s->graphs.emplace_back();
         g = &s->graphs.back();
         g->n = n;
         g->shape = sh;
-        g->dt = dt;
-        g->phase = s->cur;
         ASSERT_HIP(hipGraphCreate(&g->graph, 0), "hipGraphCreate");
-        g->nodes.resize(n);
+        g->nodes.resize((size_t)n * per_step);
         g->params.resize(n);
-        hipGraphNode_t prev = nullptr;
-        for (uint32_t i = 0; i < n; i++) {
-            g->params[i] = whole_step(s, (s->cur + i) & 1, dt);
-            void *args[] = {&g->params[i]};
-            hipKernelNodeParams kp;
-            memset(&kp, 0, sizeof kp);
-            kp.func = const_cast<void *>(nb::step_kernel_fn(sh));
-            kp.gridDim = nb::step_grid(sh, s->n_real);
-            kp.blockDim = nb::step_block(sh);
-            kp.sharedMemBytes = 0;
-            kp.kernelParams = args;
-            kp.extra = nullptr;
-            ASSERT_HIP(hipGraphAddKernelNode(&g->nodes[i], g->graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp),
-                       "hipGraphAddKernelNode %u/%u", i, n);
-            prev = g->nodes[i];
-        }
-        ASSERT_HIP(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0), "hipGraphInstantiate (%u nodes)", n);
+    } else if (g->phase == s->cur && g->dt == dt) {
         return g;
     }
-    if (g->phase != s->cur || g->dt != dt) {
-        // the analogue of the reference re-uploading its uniform when dt changes (sim_gpu.c:268-284):
-        // patch the kernel nodes instead of rebuilding the graph
-        for (uint32_t i = 0; i < n; i++) {
-            g->params[i] = whole_step(s, (s->cur + i) & 1, dt);
-            void *args[] = {&g->params[i]};
+    // (re)write every node: at creation, or -- the analogue of the reference re-uploading its uniform when dt
+    // changes (sim_gpu.c:268-284) -- patch the instantiated graph when dt or the ping-pong phase moved
+    hipGraphNode_t prev = nullptr;
+    for (uint32_t i = 0; i < n; i++) {
+        g->params[i] = shaped(s, whole_step(s, (s->cur + i) & 1, dt), sh);
+        void *args[] = {&g->params[i]};
+        for (uint32_t j = 0; j < per_step; j++) {
             hipKernelNodeParams kp;
-            memset(&kp, 0, sizeof kp);
-            kp.func = const_cast<void *>(nb::step_kernel_fn(sh));
-            kp.gridDim = nb::step_grid(sh, s->n_real);
-            kp.blockDim = nb::step_block(sh);
-            kp.kernelParams = args;
-            ASSERT_HIP(hipGraphExecKernelNodeSetParams(g->exec, g->nodes[i], &kp), "hipGraphExecKernelNodeSetParams");
+            if (j == 0)
+                fill_node(kp, args, nb::step_kernel_fn(sh), nb::step_grid(sh, s->n_real), nb::step_block(sh));
+            else
+                fill_node(kp, args, nb::finish_kernel_fn(), nb::finish_grid(s->n_real), nb::finish_block());
+            hipGraphNode_t &node = g->nodes[(size_t)i * per_step + j];
+            if (fresh) {
+                ASSERT_HIP(hipGraphAddKernelNode(&node, g->graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp),
+                           "hipGraphAddKernelNode step %u/%u", i, n);
+                prev = node;
+            } else {
+                ASSERT_HIP(hipGraphExecKernelNodeSetParams(g->exec, node, &kp), "hipGraphExecKernelNodeSetParams");
+            }
         }
-        g->phase = s->cur;
-        g->dt = dt;
     }
+    if (fresh) ASSERT_HIP(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0), "hipGraphInstantiate (%u steps)", n);
+    g->phase = s->cur;
+    g->dt = dt;
     return g;
 }
 
@@ -587,6 +620,8 @@ SimPipeline *CreateSimPipeline(WorldData data) {
     if (k) s->want_k = atoi(k);
     const char *w = getenv("NB_HIP_W");
     if (w) s->want_w = atoi(w);
+    const char *sp = getenv("NB_HIP_SPLIT");
+    if (sp) s->want_split = atoi(sp);
     const char *gr = getenv("NB_HIP_GRAPH");
     if (gr) s->use_graph = atoi(gr) ? 1 : 0;
     return s;
@@ -794,6 +829,10 @@ int nb_hip_configure(SimPipeline *s, const char *key, int value) {
                   "w must be 0, 1, 2, 4, 8 or 16, got %d", value);
         old = s->want_w;
         s->want_w = value;
+    } else if (!strcmp(key, "split")) {
+        NB_ASSERT(value >= 0 && value <= nb::MAX_SPLIT, "split must be 0 (auto) .. %d, got %d", nb::MAX_SPLIT, value);
+        old = s->want_split;
+        s->want_split = value;
     } else if (!strcmp(key, "graph")) {
         old = s->use_graph;
         s->use_graph = value ? 1 : 0;
@@ -809,8 +848,9 @@ int nb_hip_configure(SimPipeline *s, const char *key, int value) {
     return old;
 }
 
-void nb_hip_launch_shape(const SimPipeline *s, int *k, int *w, int *variant, uint32_t *workgroups) {
+void nb_hip_launch_shape(const SimPipeline *s, int *k, int *w, int *variant, int *split, uint32_t *workgroups) {
     NB_ASSERT(s != nullptr, "NULL pipeline");
+    if (split) *split = s->last_shape.split;
     if (k) *k = s->last_shape.k;
     if (w) *w = s->last_shape.w;
     if (variant) *variant = s->last_shape.variant;

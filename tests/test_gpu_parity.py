@@ -247,9 +247,38 @@ def test_deterministic(golden):
 def test_k_does_not_change_bits(golden):
     # register blocking regroups receivers, never the order sources are added in
     part, m = ob.partition(golden("ic_1024.bin"))
-    a = run(part, m, 1, 0.01, k=1, w=4)
+    a = run(part, m, 1, 0.01, k=1, w=4, split=1)
     for k in (2, 4):
-        assert run(part, m, 1, 0.01, k=k, w=4).tobytes() == a.tobytes()
+        assert run(part, m, 1, 0.01, k=k, w=4, split=1).tobytes() == a.tobytes()
+
+
+@pytest.mark.parametrize("split", [1, 2, 3, 7, 16])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_source_split_steps(golden, split, variant):
+    # gridDim.y workgroups per receiver tile + the finish kernel; parts are added in part order
+    part, m = ob.partition(golden("ic_4096.bin"))
+    got = run(part, m, 1, 0.01, split=split, variant=variant)
+    check_one_step(got, part, m, 0.01)
+    chained = run(part, m, 5, 0.01, split=split, variant=variant, graph=1)
+    plain = run(part, m, 5, 0.01, split=split, variant=variant, graph=0)
+    assert chained.tobytes() == plain.tobytes()
+
+
+def test_source_split_more_parts_than_chunks():
+    part, m = synth(300, 0.1, seed=2)       # ~30 sources = one chunk, 16 parts: most parts are empty
+    got = run(part, m, 1, 0.02, split=16)
+    check_one_step(got, part, m, 0.02)
+
+
+def test_auto_shape_reports_its_choice(golden):
+    part, m = ob.partition(golden("ic_4096.bin"))
+    sim = nb.SimPipeline(4096, m)
+    sim.set_data(part)
+    sim.update(1, 0.01)
+    shape = sim.launch_shape()
+    sim.close()
+    assert shape["k"] in (1, 2) and shape["w"] in (4, 8, 16) and 1 <= shape["split"] <= 16
+    assert shape["workgroups"] == -(-4096 // (64 * shape["k"])) * shape["split"]
 
 
 def test_acc_is_linear_in_mass_by_powers_of_two(golden):
@@ -363,11 +392,11 @@ def test_local_shard_group_single_slice_is_bitwise_equal(golden, n, P):
         assert o.tobytes() == want.tobytes()
 
 
-@pytest.mark.parametrize("overlap", [0, 1])
+@pytest.mark.parametrize("overlap,split", [(0, 0), (1, 0), (0, 3)])
 @pytest.mark.parametrize("P", [2, 8])
-def test_local_shard_group_default_shape_within_tolerance(golden, P, overlap):
+def test_local_shard_group_default_shape_within_tolerance(golden, P, overlap, split):
     part, m = ob.partition(golden("ic_4096.bin"))
-    g = nb.LocalShardGroup(4096, m, P, overlap=overlap)
+    g = nb.LocalShardGroup(4096, m, P, overlap=overlap, split=split)
     g.set_data(part)
     g.step(1, 0.01)
     got = g.get_data(P - 1)
