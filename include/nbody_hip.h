@@ -117,6 +117,14 @@ int nb_hip_configure(SimPipeline *sim, const char *key, int value);
 /* What the last step launch actually used (after "auto"): fills k, w, variant, split, workgroups. */
 void nb_hip_launch_shape(const SimPipeline *sim, int *k, int *w, int *variant, int *split, uint32_t *workgroups);
 
+/*
+ * The launch-shape arithmetic behind "auto", pure host code (usable without a GPU): for n_recv receivers and
+ * n_src sources on a chip with compute_units CUs it returns receivers per lane, waves per workgroup, source
+ * split and the resulting workgroup count.  Workgroups of one launch all take the same time, so the model
+ * minimises rounds * work-per-workgroup, rounds = ceil(workgroups / resident slots).
+ */
+void nb_hip_plan_launch(uint32_t n_recv, uint32_t n_src, int compute_units, int *k, int *w, int *split, uint32_t *workgroups);
+
 /* -- sharded (multi-GPU) pipeline: one process per GPU, N/P receivers each -- */
 
 #define NB_HIP_UNIQUE_ID_BYTES 128

@@ -50,6 +50,8 @@ HIP_API = {
     "nb_hip_configure": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "nb_hip_launch_shape": (None, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
+    "nb_hip_plan_launch": (None, [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "nb_hip_comm_unique_id": (None, [C.c_void_p]),
     "CreateSimPipelineSharded": (C.c_void_p, [WorldData, C.c_int, C.c_int, C.c_void_p]),
     "nb_hip_shard_plan": (NbShardPlan, [C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
@@ -133,6 +135,12 @@ def device_info():
 def shard_plan(total_len, mass_len, rank, nranks):
     p = hip_lib().nb_hip_shard_plan(total_len, mass_len, rank, nranks)
     return {n: int(getattr(p, n)) for n, _ in NbShardPlan._fields_}
+
+
+def plan_launch(n_recv, n_src, compute_units=256):
+    k, w, sp, g = C.c_int(), C.c_int(), C.c_int(), C.c_uint32()
+    hip_lib().nb_hip_plan_launch(n_recv, n_src, compute_units, C.byref(k), C.byref(w), C.byref(sp), C.byref(g))
+    return {"k": k.value, "w": w.value, "split": sp.value, "workgroups": g.value}
 
 
 def comm_unique_id():

@@ -655,6 +655,17 @@ SimPipeline *CreateSimPipelineSharded(WorldData data, int rank, int nranks, cons
     return s;
 }
 
+void nb_hip_plan_launch(uint32_t n_recv, uint32_t n_src, int compute_units, int *k, int *w, int *split, uint32_t *workgroups) {
+    const nb::LaunchShape sh = nb::choose_shape({0, 0, nb::VARIANT_SMEM, 0}, n_recv, n_src, compute_units);
+    if (k) *k = sh.k;
+    if (w) *w = sh.w;
+    if (split) *split = sh.split;
+    if (workgroups) {
+        const dim3 g = nb::step_grid(sh, n_recv);
+        *workgroups = g.x * g.y;
+    }
+}
+
 int nb_hip_local_group_create(WorldData data, int nranks, SimPipeline **out) {
     NB_ASSERT(nranks >= 1 && out != nullptr, "bad local group request");
     ensure_device();

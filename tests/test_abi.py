@@ -119,6 +119,23 @@ def test_shard_plan_bench_case_lands_on_round_boundaries():
             assert p["mass_count"] + p["zero_count"] == (1 << 20) // P
 
 
+def test_launch_plan_round_boundaries_and_splits():
+    # 256 CUs, two 1024-thread workgroups resident per CU = 512 slots
+    for n, m in ((1 << 20, 523884), (262144, 130916), (65536, 32641), (131072, 524288)):
+        p = nb.plan_launch(n, m)
+        assert (p["k"], p["w"], p["split"]) == (2, 16, 1) and p["workgroups"] == n // 128   # whole rounds: unsplit
+    for n, m in ((100000, 49944), (20000, 9956), (200000, 99899)):
+        p = nb.plan_launch(n, m)
+        assert p["split"] > 1 and p["workgroups"] == -(-n // (64 * p["k"])) * p["split"]    # off a boundary: split
+    for n, m in ((250, 119), (1000, 485), (4096, 1989)):
+        p = nb.plan_launch(n, m)
+        assert p["k"] == 1 and p["split"] == 1                                              # launch-bound: simplest
+    for n, m in ((1, 0), (1, 1), (64, 64), (0, 0), (4194304, 2100000), (123457, 7)):
+        p = nb.plan_launch(n, m)
+        assert p["k"] in (1, 2) and p["w"] in (4, 8, 16) and 1 <= p["split"] <= 16
+    assert nb.plan_launch(1 << 20, 523884, compute_units=0)["k"] == 2                       # 0 CUs -> default 256
+
+
 def test_gpu_call_without_gpu_aborts_loudly():
     """No CPU fallback: UpdateWorld_GPU on a box without a GPU must abort, not compute."""
     if nb.device_count() > 0:
