@@ -15,6 +15,8 @@
 //   * per interaction: v_pk_add (dx,dy), 2 fma (dist^2 + receiver radius), v_rsq_f32, 3 mul, v_pk_fma into the
 //     accumulator pair = 8 VALU instructions (10 scalar-equivalent) against the reference's 14 counted flops
 //     (SURVEY.md 8d keeps 14 as the roofline convention);
+//   * sums are two-level (64-source chunks, then Kahan over the chunk totals), so the fp32 result stays within
+//     ~1e-6 of the float64 sum at any N, ~200x closer than the reference's own AVX sums at N = 2^20;
 //   * the integrator keeps the reference's rounding (mul, then add; sim_cpu.c:191-193 /
 //     particle_cs.glsl:51-52), the force loop does not (rsq + fma instead of sqrt, div, mul, add):
 //     DESIGN.md states the tolerance.
@@ -29,60 +31,91 @@ namespace {
 
 constexpr int WAVE = 64;
 constexpr int CHUNK = 64;  // sources per staged tile = one per lane
+constexpr int CLOSE_EVERY = 4;  // tiles per summation block: plain sums over 256 sources, Kahan across blocks
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v8f __attribute__((ext_vector_type(8)));
 
+typedef float f2v __attribute__((ext_vector_type(2)));
+
 template <int K>
 struct Receivers {
-    float x[K], y[K], r[K];
-    float ax[K], ay[K];  // running sums of the current 64-source chunk
-    float sx[K], sy[K];  // sums of the finished chunks: two-level summation keeps fp32 sums of 10^5..10^6 terms
-                         // ~200x closer to float64 than the reference's 8-lane AVX sums, for 2 adds per chunk
+    f2v p[K];    // position (x, y): one aligned VGPR pair, the operand of v_pk_add_f32
+    float r[K];  // radius (softening term)
+    f2v a[K];    // running sums (ax, ay) of the current block of 256 sources: operand of v_pk_fma_f32
+    f2v s[K];    // sums of the finished blocks ...
+    f2v c[K];    // ... and their Kahan compensation
+    // Two-level summation: 256 terms per block in a[], then the block totals are added to s[] with
+    // compensated (Kahan) summation, 8 adds per block per receiver (0.4 % of a block's 2048 instructions).
+    // A plain running sum of 10^5..10^6 same-signed pulls loses 4-5 digits (the reference's 8-lane AVX sums do:
+    // profiles/r01_accuracy_vs_f64_and_avx.txt); even a plain sum of chunk totals drifts with the slice length
+    // (profiles/r01_accuracy2_shapes_before_kahan.txt).  This way the error no longer depends on N or on the
+    // launch shape.  Built without fast-math and with -ffp-contract=off, so the compensation survives.
     __device__ __forceinline__ void clear() {
 #pragma unroll
-        for (int k = 0; k < K; k++) ax[k] = ay[k] = sx[k] = sy[k] = 0.0f;
+        for (int k = 0; k < K; k++) a[k] = s[k] = c[k] = f2v{0.0f, 0.0f};
     }
     __device__ __forceinline__ void close_chunk() {
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            sx[k] += ax[k];
-            sy[k] += ay[k];
-            ax[k] = ay[k] = 0.0f;
+            const f2v y = a[k] - c[k];
+            const f2v t = s[k] + y;
+            const f2v cn = (t - s[k]) - y;
+            // a block that added exactly nothing (zero-mass pad sources of a sharded launch) must leave the
+            // state untouched, or padded and unpadded launches would differ in the last bit
+            const bool lx = a[k].x != 0.0f, ly = a[k].y != 0.0f;
+            c[k].x = lx ? cn.x : c[k].x;
+            c[k].y = ly ? cn.y : c[k].y;
+            s[k].x = lx ? t.x : s[k].x;
+            s[k].y = ly ? t.y : s[k].y;
+            a[k] = f2v{0.0f, 0.0f};
         }
     }
 };
 
-// One source against the K receivers of this lane.  sx/sy/sg are wave-uniform.
+// One source against the K receivers of this lane.  sxy/sg are wave-uniform (SGPRs).
+//
+// The eight VALU instructions of an interaction are written out as one asm statement per (source, receiver):
+//     v_pk_add_f32  d   = (sx, sy) - (x, y)
+//     v_fma_f32     q   = d.x * d.x + radius         softening: + radius of the RECEIVER, not squared
+//     v_fmac_f32    q  += d.y * d.y
+//     v_rsq_f32     q   = 1 / sqrt(q)                1 ulp; issued at raised wave priority
+//     v_mul_f32     t   = q * q
+//     v_mul_f32     u   = (G*m) * q                  G*m straight from its SGPR
+//     v_mul_f32     u   = u * t                      G*m / dist^3
+//     v_pk_fma_f32  acc += d * (u, u)                op_sel_hi broadcasts u
+// Why asm: (1) left to hipcc, the multiplies become two v_pk_mul_f32 plus a v_mov, and both the schedule and
+// the register count of the unrolled loop swing with unrelated edits (55..75 VGPRs; 65 halves the occupancy of a
+// 1024-thread workgroup): the same loop measured anywhere from 105 to 151 ms per step at N = 2^20
+// (profiles/r01_sweep_auto_split.txt, r01_sweep8_full_asm_nops_alignment.txt).  One fixed sequence on six fixed
+// temporaries cannot drift: 36 VGPRs, 108-110 ms.  (2) A v_rsq_f32 that lands between other waves' plain VALU
+// instructions costs ~16 cycles instead of 8 on gfx950; raising the wave priority for just that instruction buys
+// 2 % here (profiles/r01_ubench5_setprio_rsq.txt).  (3) gfx950 needs a wait state between a transcendental and
+// the VALU instruction that reads its result, and hipcc cannot pad inside asm: the s_nop after the rsq is ours.
+// The other dependent pairs are ordinary VALU read-after-write, which the hardware interlocks (measured: the
+// variants with and without extra s_nop all pass the parity checks; fewer is faster).  Each interaction is a serial
+// dependency chain on purpose: with 8 waves per SIMD the other waves fill the gaps, and interleaved or
+// software-pipelined orders measured slower (profiles/r01_ubench3_hand_scheduled_bodies.txt).
+// The statement is pure (no memory, not volatile); 13 instructions, 56 bytes.
 template <int K>
-__device__ __forceinline__ void interact(Receivers<K> &R, float sx, float sy, float sg) {
+__device__ __forceinline__ void interact(Receivers<K> &R, f2v sxy, float sg) {
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const float dx = sx - R.x[k];
-        const float dy = sy - R.y[k];
-        float d2 = __builtin_fmaf(dx, dx, R.r[k]);  // softening: + radius of the RECEIVER, not squared
-        d2 = __builtin_fmaf(dy, dy, d2);
-        // v_rsq_f32 (1 ulp) issued at raised wave priority: on gfx950 a transcendental sprinkled between the
-        // plain VALU instructions of the other waves of its SIMD costs ~16 cycles instead of 8; with the
-        // priority raised for just that instruction the penalty all but disappears
-        // (profiles/r01_ubench5_setprio_rsq.txt: 195 -> 143 cycles per 32 fma + 8 rsq; in this kernel +3 %,
-        // profiles/r01_sweep6_setprio_kernel.txt).
-        float inv;
-        asm("s_setprio 3\n\tv_rsq_f32 %0, %1\n\ts_setprio 0" : "=v"(inv) : "v"(d2));
-        // G*m / dist^3 as three plain v_mul_f32, pinned with asm: left alone, hipcc's SLP pass pairs them into
-        // two v_pk_mul_f32 (one of them computing f twice) plus a v_mov of G*m into a VGPR, which is slower
-        // (profiles/r01_sweep5_asm_mul_hazard_fixed.txt: +1.7 % SMEM, +11 % LDS).  gfx950 needs one wait state
-        // between a transcendental and a VALU instruction that reads its result; hipcc pads that for its own
-        // instructions but cannot see into an asm statement, so the statement carries its own s_nop (without
-        // it some lanes read a stale `inv`: the parity tests caught exactly that).  `sg` is wave-uniform in
-        // both variants ("s": the LDS route gets a v_readfirstlane).  Other placements of the priority window
-        // or fusing both statements measured no better (profiles/r01_sweep7_priority_modes.txt).
-        float inv2, f;
-        asm("s_nop 0\n\tv_mul_f32 %1, %3, %3\n\tv_mul_f32 %0, %2, %3\n\tv_mul_f32 %0, %0, %1"
-            : "=&v"(f), "=&v"(inv2)
-            : "s"(sg), "v"(inv));
-        R.ax[k] = __builtin_fmaf(dx, f, R.ax[k]);
-        R.ay[k] = __builtin_fmaf(dy, f, R.ay[k]);
+        // temporaries live in fixed registers (clobbered): d = v[30:31], q = v32, t = v33, u = v[34:35]
+        asm("v_pk_add_f32 v[30:31], %[s], %[p] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+            "v_fma_f32 v32, v30, v30, %[r]\n\t"
+            "v_fmac_f32 v32, v31, v31\n\t"
+            "s_setprio 3\n\t"
+            "v_rsq_f32 v32, v32\n\t"
+            "s_setprio 0\n\t"
+            "s_nop 0\n\t"
+            "v_mul_f32 v33, v32, v32\n\t"
+            "v_mul_f32 v34, %[g], v32\n\t"
+            "v_mul_f32 v34, v34, v33\n\t"
+            "v_pk_fma_f32 %[a], v[30:31], v[34:35], %[a] op_sel_hi:[1,0,1]"
+            : [a] "+v"(R.a[k])
+            : [s] "s"(sxy), [g] "s"(sg), [p] "v"(R.p[k]), [r] "v"(R.r[k])
+            : "v30", "v31", "v32", "v33", "v34", "v35");
     }
 }
 
@@ -93,7 +126,7 @@ __device__ __forceinline__ void interact(Receivers<K> &R, float sx, float sy, fl
 template <int K, typename VP, typename VG>
 __device__ __forceinline__ void interact8(Receivers<K> &R, const VP &P, const VG &G) {
 #pragma unroll
-    for (int u = 0; u < 8; u++) interact<K>(R, P[2 * u], P[2 * u + 1], G[u]);
+    for (int u = 0; u < 8; u++) interact<K>(R, f2v{P[2 * u], P[2 * u + 1]}, G[u]);
 }
 
 // Slot of logical receiver i (see StepParams::recv_split).
@@ -143,8 +176,11 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
     finish_receiver(p, logical, sx, sy);
 }
 
+// K <= 2 must fit 64 VGPRs: a 1024-thread workgroup puts 4 waves on every SIMD, so 65 VGPRs (7 waves/SIMD) means
+// ONE resident workgroup per CU instead of two, and hipcc's register count for this loop swings between 55 and
+// 75 with unrelated edits.  The second launch-bound argument (waves per SIMD) pins it.
 template <int K, int W, int VARIANT>
-__global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
+__global__ __launch_bounds__(WAVE *W, (K <= 2 ? 8 : 4)) void step_kernel(const StepParams p) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (WAVE - 1);
     // wave id as an SGPR value so that everything derived from it stays scalar
@@ -161,8 +197,7 @@ __global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
         i = i < p.n_recv ? i : p.n_recv - 1;  // tail lanes redo the last receiver; their stores are masked
         i = receiver_slot(p, i);
         const float2 q = p.pos_in[i];
-        R.x[k] = q.x;
-        R.y[k] = q.y;
+        R.p[k] = f2v{q.x, q.y};
         R.r[k] = p.radius[i];
     }
     R.clear();
@@ -214,9 +249,10 @@ __global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
                 const float G[8] = {G0.x, G0.y, G0.z, G0.w, G1.x, G1.y, G1.z, G1.w};
                 interact8<K>(R, P, G);
             }
-            R.close_chunk();
+            if (((c - c_lo) & (CLOSE_EVERY - 1)) == CLOSE_EVERY - 1) R.close_chunk();
             buf ^= 1;
         }
+        if ((c_hi - c_lo) & (CLOSE_EVERY - 1)) R.close_chunk();  // a short last block
     } else {
         // scalar-cache route: indices are wave-uniform, the loads become s_load_dwordx8/x16
         const uint32_t v_lo = c_lo * CHUNK;
@@ -234,9 +270,10 @@ __global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
             // multiples of 64 sources from 64-aligned range starts, so j is a multiple of 8 here.
             const float *__restrict__ sp = reinterpret_cast<const float *>(p.src_pos);
             const float *__restrict__ sg = p.src_gm;
-            // every 8 groups (64 sources) the chunk sums are closed, exactly where the LDS variant's tiles end,
-            // so both variants add in the same order; a short last chunk may end in single sources
+            // every 8 * CLOSE_EVERY groups (256 sources) the block sums are closed, exactly where the LDS variant
+            // closes them, so both variants add in the same order; a short last block may end in single sources
             const uint32_t groups = (j_end - j) / 8;
+            const uint32_t g0 = (a - v_lo) / 8;  // groups of this slice that lie in the previous range
             if (groups > 0) {
                 v16f P = *reinterpret_cast<const v16f *>(sp + 2 * (size_t)j);
                 v8f G = *reinterpret_cast<const v8f *>(sg + j);
@@ -249,12 +286,14 @@ __global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
                         G = *reinterpret_cast<const v8f *>(sg + j);
                     }
                     interact8<K>(R, Pc, Gc);
-                    if ((g & 7u) == 7u) R.close_chunk();
+                    if (((g0 + g) & (8u * CLOSE_EVERY - 1)) == 8u * CLOSE_EVERY - 1) R.close_chunk();
                 }
             }
-            for (; j < j_end; j++) interact<K>(R, sp[2 * (size_t)j], sp[2 * (size_t)j + 1], sg[j]);
-            R.close_chunk();  // the short last chunk (adds exact zeros when there is none)
+            for (; j < j_end; j++) interact<K>(R, f2v{sp[2 * (size_t)j], sp[2 * (size_t)j + 1]}, sg[j]);
         }
+        // a short last block: anything after the last multiple of 256 sources of this slice (same blocks as the
+        // LDS variant, whose last tile may be padded)
+        if ((v_hi - v_lo) & (CHUNK * CLOSE_EVERY - 1)) R.close_chunk();
     }
 
     // ---- combine the W slices in wave order, integrate, store -------------------------------------------
@@ -268,10 +307,10 @@ __global__ __launch_bounds__(WAVE *W) void step_kernel(const StepParams p) {
 
     if constexpr (W == 1) {
 #pragma unroll
-        for (int k = 0; k < K; k++) finish(recv_base + k * WAVE + lane, R.sx[k], R.sy[k]);
+        for (int k = 0; k < K; k++) finish(recv_base + k * WAVE + lane, R.s[k].x, R.s[k].y);
     } else {
 #pragma unroll
-        for (int k = 0; k < K; k++) partial[wid][k * WAVE + lane] = make_float2(R.sx[k], R.sy[k]);
+        for (int k = 0; k < K; k++) partial[wid][k * WAVE + lane] = make_float2(R.s[k].x, R.s[k].y);
         __syncthreads();
 #pragma unroll
         for (uint32_t slot = tid; slot < WAVE * K; slot += WAVE * W) {

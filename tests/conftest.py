@@ -3,6 +3,10 @@ import json
 import os
 import sys
 
+# The GPU boxes show far more cores than their CPU quota; OpenMP's default (one thread per visible core) then
+# oversubscribes the oracle and UpdateWorld_CPU by 10x.  Results do not depend on the thread count.
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+
 import numpy as np
 import pytest
 
