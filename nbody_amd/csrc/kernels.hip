@@ -8,8 +8,8 @@
 //     fixed order (deterministic results), then the workgroup integrates and stores;
 //   * sources reach the VALU wave-uniformly, 12 bytes each (x, y, G*m), by one of two routes:
 //       VARIANT_LDS   each wave stages 64-source tiles in its own LDS slab: coalesced float2/float loads
-//                     (one source per lane), ds_write, then broadcast ds_read_b128 of 4 sources per
-//                     component; double-buffered, no workgroup barrier in the loop;
+//                     (one source per lane), ds_write_b64 + b32, then broadcast ds_read_b128 (six per 8
+//                     sources); double-buffered, no workgroup barrier in the loop;
 //       VARIANT_SMEM  the wave reads its slice through the scalar cache (s_load_dwordx8/x16) so sources
 //                     arrive in SGPRs and feed the VALU as scalar operands; no LDS, no VGPR staging;
 //   * per interaction: v_pk_add (dx,dy), 2 fma (dist^2 + receiver radius), v_rsq_f32, 3 mul, v_pk_fma into the
@@ -97,25 +97,37 @@ struct Receivers {
 // dependency chain on purpose: with 8 waves per SIMD the other waves fill the gaps, and interleaved or
 // software-pipelined orders measured slower (profiles/r01_ubench3_hand_scheduled_bodies.txt).
 // The statement is pure (no memory, not volatile); 13 instructions, 56 bytes.
-template <int K>
+#define NB_INTERACTION_ASM                                                      \
+    "v_pk_add_f32 v[30:31], %[s], %[p] neg_lo:[0,1] neg_hi:[0,1]\n\t"          \
+    "v_fma_f32 v32, v30, v30, %[r]\n\t"                                        \
+    "v_fmac_f32 v32, v31, v31\n\t"                                             \
+    "s_setprio 3\n\t"                                                          \
+    "v_rsq_f32 v32, v32\n\t"                                                   \
+    "s_setprio 0\n\t"                                                          \
+    "s_nop 0\n\t"                                                              \
+    "v_mul_f32 v33, v32, v32\n\t"                                              \
+    "v_mul_f32 v34, %[g], v32\n\t"                                             \
+    "v_mul_f32 v34, v34, v33\n\t"                                              \
+    "v_pk_fma_f32 %[a], v[30:31], v[34:35], %[a] op_sel_hi:[1,0,1]"
+
+// SRC_IN_SGPR: the source sits in SGPRs (scalar-cache route) or in VGPRs holding a wave-uniform value
+// (LDS broadcast reads); the instructions are the same, only the operand class differs.
+template <int K, bool SRC_IN_SGPR>
 __device__ __forceinline__ void interact(Receivers<K> &R, f2v sxy, float sg) {
 #pragma unroll
     for (int k = 0; k < K; k++) {
         // temporaries live in fixed registers (clobbered): d = v[30:31], q = v32, t = v33, u = v[34:35]
-        asm("v_pk_add_f32 v[30:31], %[s], %[p] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-            "v_fma_f32 v32, v30, v30, %[r]\n\t"
-            "v_fmac_f32 v32, v31, v31\n\t"
-            "s_setprio 3\n\t"
-            "v_rsq_f32 v32, v32\n\t"
-            "s_setprio 0\n\t"
-            "s_nop 0\n\t"
-            "v_mul_f32 v33, v32, v32\n\t"
-            "v_mul_f32 v34, %[g], v32\n\t"
-            "v_mul_f32 v34, v34, v33\n\t"
-            "v_pk_fma_f32 %[a], v[30:31], v[34:35], %[a] op_sel_hi:[1,0,1]"
-            : [a] "+v"(R.a[k])
-            : [s] "s"(sxy), [g] "s"(sg), [p] "v"(R.p[k]), [r] "v"(R.r[k])
-            : "v30", "v31", "v32", "v33", "v34", "v35");
+        if constexpr (SRC_IN_SGPR) {
+            asm(NB_INTERACTION_ASM
+                : [a] "+v"(R.a[k])
+                : [s] "s"(sxy), [g] "s"(sg), [p] "v"(R.p[k]), [r] "v"(R.r[k])
+                : "v30", "v31", "v32", "v33", "v34", "v35");
+        } else {
+            asm(NB_INTERACTION_ASM
+                : [a] "+v"(R.a[k])
+                : [s] "v"(sxy), [g] "v"(sg), [p] "v"(R.p[k]), [r] "v"(R.r[k])
+                : "v30", "v31", "v32", "v33", "v34", "v35");
+        }
     }
 }
 
@@ -123,10 +135,10 @@ __device__ __forceinline__ void interact(Receivers<K> &R, f2v sxy, float sg) {
 // instructions is left to the compiler: forcing the 8*K v_rsq_f32 into back-to-back runs with
 // sched_barrier phases measured 7-8 % slower (profiles/r01_sweep1_grouping_slp.txt), although isolated
 // runs of transcendentals are cheaper than sprinkled ones (profiles/r01_ubench2_rsq_mixing.txt).
-template <int K, typename VP, typename VG>
+template <int K, bool SRC_IN_SGPR, typename VP, typename VG>
 __device__ __forceinline__ void interact8(Receivers<K> &R, const VP &P, const VG &G) {
 #pragma unroll
-    for (int u = 0; u < 8; u++) interact<K>(R, f2v{P[2 * u], P[2 * u + 1]}, G[u]);
+    for (int u = 0; u < 8; u++) interact<K, SRC_IN_SGPR>(R, f2v{P[2 * u], P[2 * u + 1]}, G[u]);
 }
 
 // Slot of logical receiver i (see StepParams::recv_split).
@@ -187,7 +199,8 @@ __global__ __launch_bounds__(WAVE *W, (K <= 2 ? 8 : 4)) void step_kernel(const S
     const uint32_t wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t recv_base = blockIdx.x * (WAVE * K);
 
-    __shared__ __attribute__((aligned(16))) float tile[VARIANT == VARIANT_LDS ? W : 1][2][3][CHUNK];
+    // per wave, double-buffered: 64 interleaved (x, y) pairs, then 64 G*m
+    __shared__ __attribute__((aligned(16))) float tile[VARIANT == VARIANT_LDS ? W : 1][2][3 * CHUNK];
     __shared__ float2 partial[W > 1 ? W : 1][W > 1 ? WAVE * K : 1];
 
     Receivers<K> R;
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(WAVE *W, (K <= 2 ? 8 : 4)) void step_kernel(const S
     const uint32_t c_hi = min(c_lo + per_wave, part_hi);
 
     if constexpr (VARIANT == VARIANT_LDS) {
-        float(*T)[3][CHUNK] = tile[wid];
+        float(*T)[3 * CHUNK] = tile[wid];
         float2 sp = make_float2(0.f, 0.f);
         float sg = 0.f;
         auto fetch = [&](uint32_t c) {
@@ -229,25 +242,18 @@ __global__ __launch_bounds__(WAVE *W, (K <= 2 ? 8 : 4)) void step_kernel(const S
         if (c_lo < c_hi) fetch(c_lo);
         int buf = 0;
         for (uint32_t c = c_lo; c < c_hi; c++) {
-            T[buf][0][lane] = sp.x;
-            T[buf][1][lane] = sp.y;
-            T[buf][2][lane] = sg;
+            *reinterpret_cast<float2 *>(&T[buf][2 * lane]) = sp;  // ds_write_b64
+            T[buf][2 * CHUNK + lane] = sg;
             if (c + 1 < c_hi) fetch(c + 1);  // next tile's HBM/L2 latency hides under this tile's math
             // LDS executes one wave's accesses in order; this only stops the compiler from reordering
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (int jj = 0; jj < CHUNK; jj += 8) {
-                const float4 X0 = *reinterpret_cast<const float4 *>(&T[buf][0][jj]);  // broadcast ds_read_b128
-                const float4 X1 = *reinterpret_cast<const float4 *>(&T[buf][0][jj + 4]);
-                const float4 Y0 = *reinterpret_cast<const float4 *>(&T[buf][1][jj]);
-                const float4 Y1 = *reinterpret_cast<const float4 *>(&T[buf][1][jj + 4]);
-                const float4 G0 = *reinterpret_cast<const float4 *>(&T[buf][2][jj]);
-                const float4 G1 = *reinterpret_cast<const float4 *>(&T[buf][2][jj + 4]);
-                const float P[16] = {X0.x, Y0.x, X0.y, Y0.y, X0.z, Y0.z, X0.w, Y0.w,
-                                     X1.x, Y1.x, X1.y, Y1.y, X1.z, Y1.z, X1.w, Y1.w};
-                const float G[8] = {G0.x, G0.y, G0.z, G0.w, G1.x, G1.y, G1.z, G1.w};
-                interact8<K>(R, P, G);
+                // broadcast ds_read_b128: every lane reads the same 16 bytes; (x, y) pairs land in aligned VGPR pairs
+                const v16f P = *reinterpret_cast<const v16f *>(&T[buf][2 * jj]);
+                const v8f G = *reinterpret_cast<const v8f *>(&T[buf][2 * CHUNK + jj]);
+                interact8<K, false>(R, P, G);
             }
             if (((c - c_lo) & (CLOSE_EVERY - 1)) == CLOSE_EVERY - 1) R.close_chunk();
             buf ^= 1;
@@ -285,11 +291,11 @@ __global__ __launch_bounds__(WAVE *W, (K <= 2 ? 8 : 4)) void step_kernel(const S
                         P = *reinterpret_cast<const v16f *>(sp + 2 * (size_t)j);
                         G = *reinterpret_cast<const v8f *>(sg + j);
                     }
-                    interact8<K>(R, Pc, Gc);
+                    interact8<K, true>(R, Pc, Gc);
                     if (((g0 + g) & (8u * CLOSE_EVERY - 1)) == 8u * CLOSE_EVERY - 1) R.close_chunk();
                 }
             }
-            for (; j < j_end; j++) interact<K>(R, f2v{sp[2 * (size_t)j], sp[2 * (size_t)j + 1]}, sg[j]);
+            for (; j < j_end; j++) interact<K, true>(R, f2v{sp[2 * (size_t)j], sp[2 * (size_t)j + 1]}, sg[j]);
         }
         // a short last block: anything after the last multiple of 256 sources of this slice (same blocks as the
         // LDS variant, whose last tile may be padded)
