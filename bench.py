@@ -119,8 +119,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=N_PARTICLES, help="particles (default 2^20, the metric's size)")
+    ap.add_argument("--particles", dest="n", type=int, default=N_PARTICLES,
+                    help="particles (default 2^20, the size the metric is quoted on); not --n: torchrun claims that prefix")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearse the multi-rank control flow (rendezvous, id broadcast, barriers, reduction, JSON) "
+                         "without touching a GPU: no step runs and the reported value is 0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,7 +154,9 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    nb.hip_lib().nb_hip_set_device(local_rank)
+    if not args.dry_run:
+        ndev = nb.device_count()
+        nb.hip_lib().nb_hip_set_device(local_rank if local_rank < max(ndev, 1) else local_rank % max(ndev, 1))
     part, mass_len = make_workload(args.n)
     n = part.shape[0]
 
@@ -166,19 +172,30 @@ def main():
             raw = bytearray(buf.numpy().tobytes())
         uid = bytes(raw)
 
-    sim = nb.SimPipeline(n, mass_len, rank=rank, nranks=world, unique_id=uid if sharded else None)
-    sim.set_data(part)           # H2D + SoA split: outside the timed region
+    if args.dry_run:
+        assert uid is None or len(uid) == nb.UNIQUE_ID_BYTES
+        plan = nb.shard_plan(n, mass_len, rank, world)
+        assert plan["mass_count"] + plan["zero_count"] > 0 or n < world
+        barrier()
+        t0 = time.perf_counter()
+        barrier()
+        elapsed = max(time.perf_counter() - t0, 1e-9)
+        kernel_ms, launches = 0.0, 0
+        shape, info, sim = nb.plan_launch(plan["mass_count"] + plan["zero_count"], plan["src_padded"]), "dry-run", None
+    else:
+        sim = nb.SimPipeline(n, mass_len, rank=rank, nranks=world, unique_id=uid if sharded else None)
+        sim.set_data(part)           # H2D + SoA split: outside the timed region
 
-    if args.warmup > 0:
-        sim.update(args.warmup, DT)
-    barrier()
-    sim.sync()
-    t0 = time.perf_counter()
-    sim.update(args.steps, DT)   # ONE call, K steps, blocking (hipGraph chain / RCCL-stepped chain)
-    sim.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, launches = sim.last_step_ms()
+        if args.warmup > 0:
+            sim.update(args.warmup, DT)
+        barrier()
+        sim.sync()
+        t0 = time.perf_counter()
+        sim.update(args.steps, DT)   # ONE call, K steps, blocking (hipGraph chain / RCCL-stepped chain)
+        sim.sync()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kernel_ms, launches = sim.last_step_ms()
 
     if dist is not None:
         import torch
@@ -187,13 +204,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    shape = sim.launch_shape()
-    info = nb.device_info()
-    sim.close()
+    if sim is not None:
+        shape = sim.launch_shape()
+        info = nb.device_info()
+        sim.close()
 
     if rank == 0:
         interactions = float(n) * float(mass_len) * args.steps
-        value = interactions / elapsed
+        value = 0.0 if args.dry_run else interactions / elapsed
         # dominant kernel: the step kernel; algorithmic flops per launch = interactions per launch * 14
         per_launch_s = (kernel_ms * 1e-3) / max(launches, 1)
         launch_interactions = float(n) * float(mass_len) / world * (args.steps / max(launches, 1))
@@ -232,7 +250,7 @@ def main():
                 "launches": launches,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline(part, mass_len)
         print(json.dumps(out), flush=True)
 

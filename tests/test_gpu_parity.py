@@ -321,6 +321,32 @@ def test_single_source_known_answer():
     assert np.allclose(got[1, 0:2], [0.0, 0.0], atol=1e-6)
 
 
+def test_zero_radius_singularities_match_the_reference():
+    # reference behaviour (SURVEY.md 8a "edge semantics"): radius == 0 plus a coincident source is not guarded:
+    # 0 * inf = NaN.  A massive body with radius 0 meets itself; a tracer with radius 0 sits on a source.
+    a = np.zeros((4, 8), dtype=np.float32)
+    a[:, 0] = [0.0, 50.0, 50.0, 90.0]
+    a[:, 6] = [5.0, 7.0, 0.0, 0.0]
+    a[:, 7] = [0.0, 1.0, 0.0, 0.5]          # body 0: radius 0 (self-hit); tracer 2: radius 0 on top of body 1
+    part, m = ob.partition(a)
+    want = ob.step(part, m, 0.1, 1)
+    got = run(part, m, 0.1, 1)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.isnan(got[0, 4]) and np.isnan(got[2, 4]) and not np.isnan(got[1, 4]) and not np.isnan(got[3, 4])
+    ok = ~np.isnan(want)
+    assert np.allclose(got[ok], want[ok], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_small_worlds(seed):
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(1, 700))
+    part, m = synth(n, float(rng.random()), seed=seed, extent=float(10 ** rng.uniform(1, 5)))
+    dt = float(10 ** rng.uniform(-3, -1))
+    got = run(part, m, 1, dt, variant=seed & 1, split=int(rng.integers(0, 5)))
+    check_one_step(got, part, m, dt)
+
+
 def test_negative_mass_is_massless():
     a = np.zeros((3, 8), dtype=np.float32)
     a[:, 7] = 1.0

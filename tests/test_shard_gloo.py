@@ -26,3 +26,24 @@ def test_sharded_exchange_reproduces_single_rank(tmp_path, golden, world, n):
     want = ob.step(part, m, dt, steps)
     # pos/vel/mass/radius of every particle and acc of everything: bit-exact with the unsharded run
     assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_multi_rank_control_flow_dry_run(world):
+    """bench.py under torch.distributed.run, world_size > 1, no GPU: rendezvous, RCCL-id broadcast over gloo,
+    barriers, max-over-ranks reduction and the one JSON line on rank 0 (the sharded device work is skipped)."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29610 + world),
+           os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--particles", "65536",
+           "--dry-run"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "strong"
+    assert out["unit"] == "interactions/s" and out["dtype"] == "f32" and "roofline" in out and "cpu_baseline" not in out
+    assert f"N/{world}" in out["config"]["parallelism"]
