@@ -330,7 +330,7 @@ def test_zero_radius_singularities_match_the_reference():
     a[:, 7] = [0.0, 1.0, 0.0, 0.5]          # body 0: radius 0 (self-hit); tracer 2: radius 0 on top of body 1
     part, m = ob.partition(a)
     want = ob.step(part, m, 0.1, 1)
-    got = run(part, m, 0.1, 1)
+    got = run(part, m, 1, 0.1)
     assert np.array_equal(np.isnan(got), np.isnan(want))
     assert np.isnan(got[0, 4]) and np.isnan(got[2, 4]) and not np.isnan(got[1, 4]) and not np.isnan(got[3, 4])
     ok = ~np.isnan(want)
