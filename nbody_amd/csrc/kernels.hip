@@ -15,8 +15,9 @@
 //   * per interaction: v_pk_add (dx,dy), 2 fma (dist^2 + receiver radius), v_rsq_f32, 3 mul, v_pk_fma into the
 //     accumulator pair = 8 VALU instructions (10 scalar-equivalent) against the reference's 14 counted flops
 //     (SURVEY.md 8d keeps 14 as the roofline convention);
-//   * sums are two-level (64-source chunks, then Kahan over the chunk totals), so the fp32 result stays within
-//     ~1e-6 of the float64 sum at any N, ~200x closer than the reference's own AVX sums at N = 2^20;
+//   * sums are two-level (plain over blocks of 256 sources, then Kahan over the block totals), so the fp32 result
+//     stays within ~4e-7 * sum|contribution| (rms) of the float64 sum at any N and launch shape, 180x closer than
+//     the reference's own AVX sums at N = 2^20;
 //   * the integrator keeps the reference's rounding (mul, then add; sim_cpu.c:191-193 /
 //     particle_cs.glsl:51-52), the force loop does not (rsq + fma instead of sqrt, div, mul, add):
 //     DESIGN.md states the tolerance.
@@ -131,10 +132,7 @@ __device__ __forceinline__ void interact(Receivers<K> &R, f2v sxy, float sg) {
     }
 }
 
-// 8 sources (x,y interleaved in P, G*m in G) against the K receivers.  The order of the 80*K VALU
-// instructions is left to the compiler: forcing the 8*K v_rsq_f32 into back-to-back runs with
-// sched_barrier phases measured 7-8 % slower (profiles/r01_sweep1_grouping_slp.txt), although isolated
-// runs of transcendentals are cheaper than sprinkled ones (profiles/r01_ubench2_rsq_mixing.txt).
+// 8 sources (x,y interleaved in P, G*m in G) against the K receivers: 8*K interaction statements, source-major.
 template <int K, bool SRC_IN_SGPR, typename VP, typename VG>
 __device__ __forceinline__ void interact8(Receivers<K> &R, const VP &P, const VG &G) {
 #pragma unroll
@@ -188,9 +186,9 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
     finish_receiver(p, logical, sx, sy);
 }
 
-// K <= 2 must fit 64 VGPRs: a 1024-thread workgroup puts 4 waves on every SIMD, so 65 VGPRs (7 waves/SIMD) means
-// ONE resident workgroup per CU instead of two, and hipcc's register count for this loop swings between 55 and
-// 75 with unrelated edits.  The second launch-bound argument (waves per SIMD) pins it.
+// K <= 2 must stay within 64 VGPRs: a 1024-thread workgroup puts 4 waves on every SIMD, so 65 VGPRs (7 waves per
+// SIMD) would mean ONE resident workgroup per CU instead of two.  The asm body needs 36 (SMEM) / 62 (LDS); the
+// second launch-bound argument (waves per SIMD) makes the limit explicit.
 template <int K, int W, int VARIANT>
 __global__ __launch_bounds__(WAVE *W, (K <= 2 ? 8 : 4)) void step_kernel(const StepParams p) {
     const uint32_t tid = threadIdx.x;
