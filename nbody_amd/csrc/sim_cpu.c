@@ -13,14 +13,55 @@
  * which halves the load traffic of the reference's one-receiver loop without
  * touching the per-receiver arithmetic.
  *
+ * SIMD_SET, like the reference's CMake option (CMakeLists.txt:4, src/lib/CMakeLists.txt:24-33): the default
+ * build is AVX (8 lanes); -DNB_SIMD_SSE gives the reference's SSE build (4 lanes), -DNB_SIMD_NONE its scalar
+ * build (1 lane = sources in index order).  Each is bit-exact with the corresponding reference build.
+ *
  * Build: -mavx -ffp-contract=off (no FMA contraction), see csrc/Makefile.
  */
 #include "sim_cpu.h"
 #include "nb_util.h"
 
+#if defined(NB_SIMD_SSE)
+#include <xmmintrin.h>
+#define V 4u /* floats per vector */
+typedef __m128 vf;
+#define vf_set1 _mm_set1_ps
+#define vf_zero _mm_setzero_ps
+#define vf_load _mm_load_ps
+#define vf_storeu _mm_storeu_ps
+#define vf_add _mm_add_ps
+#define vf_sub _mm_sub_ps
+#define vf_mul _mm_mul_ps
+#define vf_div _mm_div_ps
+#define vf_sqrt _mm_sqrt_ps
+#elif defined(NB_SIMD_NONE)
+#include <math.h>
+#define V 1u
+typedef float vf;
+#define vf_set1(x) (x)
+#define vf_zero() 0.0f
+#define vf_load(p) (*(p))
+#define vf_storeu(p, x) (*(p) = (x))
+#define vf_add(a, b) ((a) + (b))
+#define vf_sub(a, b) ((a) - (b))
+#define vf_mul(a, b) ((a) * (b))
+#define vf_div(a, b) ((a) / (b))
+#define vf_sqrt(a) sqrtf(a)
+#else /* AVX: the reference's default build and the parity target */
 #include <immintrin.h>
-
-#define V 8u /* floats per __m256 */
+#define V 8u
+typedef __m256 vf;
+#define vf_set1 _mm256_set1_ps
+#define vf_zero _mm256_setzero_ps
+#define vf_load _mm256_load_ps
+#define vf_storeu _mm256_storeu_ps
+#define vf_add _mm256_add_ps
+#define vf_sub _mm256_sub_ps
+#define vf_mul _mm256_mul_ps
+#define vf_div _mm256_div_ps
+#define vf_sqrt _mm256_sqrt_ps
+#endif
 
 struct CpuSim {
     float *sx, *sy, *sm; /* snapshot, 32-byte aligned, zero-padded to a multiple of V */
@@ -31,7 +72,7 @@ CpuSim *CpuSimCreate(uint32_t mass_len) {
     CpuSim *sim = NB_NEW(1, CpuSim);
     NB_CHECK(sim != NULL, "Failed to alloc CpuSim");
     sim->capacity = (mass_len + V - 1u) / V * V;
-    size_t bytes = (size_t)(sim->capacity ? sim->capacity : V) * sizeof(float);
+    size_t bytes = ((size_t)(sim->capacity ? sim->capacity : V) * sizeof(float) + 31u) / 32u * 32u;
     sim->sx = (float *)aligned_alloc(32, bytes);
     sim->sy = (float *)aligned_alloc(32, bytes);
     sim->sm = (float *)aligned_alloc(32, bytes);
@@ -47,10 +88,10 @@ void CpuSimDestroy(CpuSim *sim) {
     free(sim);
 }
 
-/* lanes 7..0 added onto 0: the reference's element order 0..7 in our lane numbering */
-static inline float hsum_ref_order(__m256 v) {
+/* lanes V-1..0 added onto 0: the reference's element order 0..V-1 in our lane numbering */
+static inline float hsum_ref_order(vf v) {
     float lane[V];
-    _mm256_storeu_ps(lane, v);
+    vf_storeu(lane, v);
     float s = 0.0f;
     for (int e = (int)V - 1; e >= 0; e--) s += lane[e];
     return s;
@@ -62,17 +103,16 @@ static inline void euler(Particle *p, float ax, float ay, float dt) {
     p->pos = AddV2(p->pos, ScaleV2(p->vel, dt));
 }
 
-#define PAIR_TERM(X, Y, R, AX, AY)                                   \
-    do {                                                             \
-        __m256 dx = _mm256_sub_ps(px, X);                            \
-        __m256 dy = _mm256_sub_ps(py, Y);                            \
-        __m256 d2 = _mm256_add_ps(_mm256_mul_ps(dx, dx),             \
-                                  _mm256_mul_ps(dy, dy));            \
-        __m256 r2 = _mm256_add_ps(d2, R);                            \
-        __m256 r3 = _mm256_mul_ps(_mm256_sqrt_ps(r2), r2);           \
-        __m256 f = _mm256_div_ps(gm, r3);                            \
-        AX = _mm256_add_ps(AX, _mm256_mul_ps(dx, f));                \
-        AY = _mm256_add_ps(AY, _mm256_mul_ps(dy, f));                \
+#define PAIR_TERM(X, Y, R, AX, AY)                          \
+    do {                                                    \
+        vf dx = vf_sub(px, X);                              \
+        vf dy = vf_sub(py, Y);                              \
+        vf d2 = vf_add(vf_mul(dx, dx), vf_mul(dy, dy));     \
+        vf r2 = vf_add(d2, R);                              \
+        vf r3 = vf_mul(vf_sqrt(r2), r2);                    \
+        vf f = vf_div(gm, r3);                              \
+        AX = vf_add(AX, vf_mul(dx, f));                     \
+        AY = vf_add(AY, vf_mul(dy, f));                     \
     } while (0)
 
 void CpuSimStep(CpuSim *sim, Particle *arr, uint32_t total_len, uint32_t mass_len, float dt) {
@@ -93,17 +133,17 @@ void CpuSimStep(CpuSim *sim, Particle *arr, uint32_t total_len, uint32_t mass_le
         sm[j] = live ? arr[j].mass : 0.0f;
     }
 
-    const __m256 g = _mm256_set1_ps(NB_G);
+    const vf g = vf_set1(NB_G);
     const uint32_t pairs = total_len / 2u;
 #pragma omp parallel for schedule(static, 16) if (go_parallel)
     for (uint32_t q = 0; q < pairs; q++) {
         Particle *a = &arr[2u * q], *b = a + 1;
-        const __m256 xa = _mm256_set1_ps(a->pos.x), ya = _mm256_set1_ps(a->pos.y), ra = _mm256_set1_ps(a->radius);
-        const __m256 xb = _mm256_set1_ps(b->pos.x), yb = _mm256_set1_ps(b->pos.y), rb = _mm256_set1_ps(b->radius);
-        __m256 axa = _mm256_setzero_ps(), aya = axa, axb = axa, ayb = axa;
+        const vf xa = vf_set1(a->pos.x), ya = vf_set1(a->pos.y), ra = vf_set1(a->radius);
+        const vf xb = vf_set1(b->pos.x), yb = vf_set1(b->pos.y), rb = vf_set1(b->radius);
+        vf axa = vf_zero(), aya = axa, axb = axa, ayb = axa;
         for (uint32_t j = 0; j < padded; j += V) {
-            const __m256 px = _mm256_load_ps(sx + j), py = _mm256_load_ps(sy + j);
-            const __m256 gm = _mm256_mul_ps(_mm256_load_ps(sm + j), g);
+            const vf px = vf_load(sx + j), py = vf_load(sy + j);
+            const vf gm = vf_mul(vf_load(sm + j), g);
             PAIR_TERM(xa, ya, ra, axa, aya);
             PAIR_TERM(xb, yb, rb, axb, ayb);
         }
@@ -112,11 +152,11 @@ void CpuSimStep(CpuSim *sim, Particle *arr, uint32_t total_len, uint32_t mass_le
     }
     if (total_len & 1u) {
         Particle *a = &arr[total_len - 1u];
-        const __m256 xa = _mm256_set1_ps(a->pos.x), ya = _mm256_set1_ps(a->pos.y), ra = _mm256_set1_ps(a->radius);
-        __m256 axa = _mm256_setzero_ps(), aya = axa;
+        const vf xa = vf_set1(a->pos.x), ya = vf_set1(a->pos.y), ra = vf_set1(a->radius);
+        vf axa = vf_zero(), aya = axa;
         for (uint32_t j = 0; j < padded; j += V) {
-            const __m256 px = _mm256_load_ps(sx + j), py = _mm256_load_ps(sy + j);
-            const __m256 gm = _mm256_mul_ps(_mm256_load_ps(sm + j), g);
+            const vf px = vf_load(sx + j), py = vf_load(sy + j);
+            const vf gm = vf_mul(vf_load(sm + j), g);
             PAIR_TERM(xa, ya, ra, axa, aya);
         }
         euler(a, hsum_ref_order(axa), hsum_ref_order(aya), dt);

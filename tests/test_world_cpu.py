@@ -144,3 +144,30 @@ def test_reference_world_c_runs_on_our_shim_cpu_side(golden, manifest):
     got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n.value, 8)).copy()
     ref.DestroyWorld(w)
     assert ob.sha256(got) == manifest["survey_digests"]["4096_s1_dt0.01"]
+
+
+@pytest.mark.parametrize("name,so", [("sse", "libnbody_sse.so"), ("scalar", "libnbody_scalar.so")])
+def test_other_simd_set_builds_match_their_reference_builds(manifest, golden, name, so):
+    """SIMD_SET=SSE / none builds of the World library against digests of the reference's same builds."""
+    nb.hip_lib()
+    lib = C.CDLL(os.path.join(nb.LIB_DIR, so))
+    lib.CreateWorld.restype = C.c_void_p
+    lib.CreateWorld.argtypes = [C.c_void_p, C.c_uint32]
+    lib.GetWorldParticles.restype = C.c_void_p
+    lib.GetWorldParticles.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    lib.UpdateWorld_CPU.argtypes = [C.c_void_p, C.c_float, C.c_uint32]
+    lib.DestroyWorld.argtypes = [C.c_void_p]
+    seen = 0
+    for tag, e in manifest["simd_variants"].items():
+        if not tag.startswith(name + "_"):
+            continue
+        ic = golden(f"ic_{e['n']}.bin")
+        w = lib.CreateWorld(ic.ctypes.data, e["n"])
+        lib.UpdateWorld_CPU(w, e["dt"], e["n_steps"])
+        n = C.c_uint32()
+        p = lib.GetWorldParticles(w, C.byref(n))
+        got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n.value, 8)).copy()
+        lib.DestroyWorld(w)
+        assert ob.sha256(got) == e["sha256"], tag
+        seen += 1
+    assert seen == 4
