@@ -108,6 +108,8 @@ double nb_hip_last_step_ms(SimPipeline *sim, uint32_t *launches);
  *   "split"     workgroups per receiver tile, each over 1/split of the sources (a second small kernel adds
  *               the parts and integrates): 0 = auto (fills the chip / lands on a round boundary), else 1..16
  *   "graph"     1 = run step chains as hipGraphs (default), 0 = plain stream launches
+ *   "sharded_graph"  sharded pipelines: 1 = capture the {kernel, all-gather} x n chain into a hipGraph and replay
+ *               it (non-overlapped step only); 0 = plain stream launches (default)
  *   "overlap"   sharded pipelines: 1 = split each step into own-shard / remote-shard kernels
  *               with the all-gather in between on a second stream, 0 = gather then one kernel
  * Returns the previous value; aborts on an unknown key or value.

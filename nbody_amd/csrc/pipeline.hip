@@ -204,7 +204,7 @@ struct SimPipeline {
 
     // knobs
     int want_variant = nb::VARIANT_SMEM, want_k = 0, want_w = 0, want_split = 0;  // SMEM measures 2.5 % faster than LDS tiles
-    int use_graph = 1, overlap = 0;
+    int use_graph = 1, overlap = 0, sharded_graph = 0;
     nb::LaunchShape last_shape = {0, 0, 0, 0};
     uint32_t last_groups = 0;
 
@@ -501,9 +501,44 @@ void sharded_step(SimPipeline *s, nb::LaunchShape sh, float dt, hipStream_t cs) 
     s->cur ^= 1;
 }
 
+// Opt-in ("sharded_graph"): the chain of {step kernel(s), in-place all-gather} x n captured from the stream into a
+// hipGraph and replayed, like the single-GPU chains.  Only the in-stream (non-overlapped) step is captured; an even
+// chain length keeps the ping-pong phase so a cached graph can be replayed as is.  Off by default: RCCL inside
+// stream capture is the least-travelled path of this library (exercised with one rank only, tests).
+StepGraph *capture_sharded_chain(SimPipeline *s, uint32_t n, float dt, nb::LaunchShape sh) {
+    for (auto &c : s->graphs)
+        if (c.n == n && c.dt == dt && c.phase == s->cur && c.shape.k == sh.k && c.shape.w == sh.w &&
+            c.shape.variant == sh.variant && c.shape.split == sh.split)
+            return &c;
+    s->graphs.emplace_back();
+    StepGraph *g = &s->graphs.back();
+    g->n = n;
+    g->dt = dt;
+    g->phase = s->cur;
+    g->shape = sh;
+    const int cur0 = s->cur;
+    ASSERT_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+    for (uint32_t i = 0; i < n; i++) sharded_step(s, sh, dt, s->stream);
+    ASSERT_HIP(hipStreamEndCapture(s->stream, &g->graph), "hipStreamEndCapture");
+    ASSERT_HIP(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0), "hipGraphInstantiate (sharded, %u steps)", n);
+    s->cur = cur0;  // capture only recorded the work; the replay below advances the phase
+    return g;
+}
+
 void enqueue_sharded(SimPipeline *s, uint32_t n, float dt) {
     NB_ASSERT(s->group == nullptr, "members of a local group step through nb_hip_local_group_step");
     const nb::LaunchShape sh = resolve_shape(s);
+    if (s->sharded_graph && !s->overlap && n > 1) {
+        uint32_t left = n;
+        while (left > 0) {
+            const uint32_t chunk = left > GRAPH_CHAIN_MAX ? GRAPH_CHAIN_MAX : left;
+            StepGraph *g = capture_sharded_chain(s, chunk, dt, sh);
+            ASSERT_HIP(hipGraphLaunch(g->exec, s->stream), "hipGraphLaunch (sharded, %u steps)", chunk);
+            if (chunk & 1) s->cur ^= 1;
+            left -= chunk;
+        }
+        return;
+    }
     for (uint32_t i = 0; i < n; i++) sharded_step(s, sh, dt, s->comm_stream);
     if (s->overlap) ASSERT_HIP(hipStreamWaitEvent(s->stream, s->ev_gather, 0), "join comm stream");
 }
@@ -648,6 +683,8 @@ SimPipeline *CreateSimPipelineSharded(WorldData data, int rank, int nranks, cons
     s->plan = nb_hip_shard_plan(data.total_len, data.mass_len, rank, nranks);
     const char *ov = getenv("NB_HIP_OVERLAP");
     if (ov) s->overlap = atoi(ov) ? 1 : 0;
+    const char *sg = getenv("NB_HIP_SHARDED_GRAPH");
+    if (sg) s->sharded_graph = atoi(sg) ? 1 : 0;
     ensure_device();  // the communicator binds to the current device
     ncclUniqueId id;
     memcpy(&id, unique_id128, NB_HIP_UNIQUE_ID_BYTES);
@@ -847,6 +884,9 @@ int nb_hip_configure(SimPipeline *s, const char *key, int value) {
     } else if (!strcmp(key, "graph")) {
         old = s->use_graph;
         s->use_graph = value ? 1 : 0;
+    } else if (!strcmp(key, "sharded_graph")) {
+        old = s->sharded_graph;
+        s->sharded_graph = value ? 1 : 0;
     } else if (!strcmp(key, "overlap")) {
         old = s->overlap;
         if (s->on_device && s->sharded) nb_hip_sync(s);

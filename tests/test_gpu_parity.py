@@ -467,7 +467,8 @@ def test_local_shard_group_ragged(golden):
 
 
 def test_rccl_path_with_one_rank_in_a_subprocess(golden, tmp_path):
-    """NB_HIP_FORCE_SHARDED=1: dlopen librccl, ncclCommInitRank(1 rank), in-place all-gathers, both step modes."""
+    """NB_HIP_FORCE_SHARDED=1: dlopen librccl, ncclCommInitRank(1 rank), in-place all-gathers; plain, overlapped and
+    hipGraph-captured chains."""
     code = r'''
 import os, sys, numpy as np
 sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, %(root)r)
@@ -477,18 +478,19 @@ part, m = ob.partition(ic)
 uid = nb.comm_unique_id()
 L = nb.hip_lib()
 outs = []
-for overlap in (0, 1):
+for overlap, sgraph in ((0, 0), (1, 0), (0, 1)):
     sim = nb.SimPipeline.__new__(nb.SimPipeline)
     import ctypes as C
-    buf = (C.c_ubyte * 128).from_buffer_copy(uid if overlap == 0 else nb.comm_unique_id())
+    buf = (C.c_ubyte * 128).from_buffer_copy(nb.comm_unique_id())
     sim._h = L.CreateSimPipelineSharded(nb.WorldData(1024, m, 0.0), 0, 1, buf)
     sim.total_len, sim.mass_len, sim.rank, sim.nranks = 1024, m, 0, 1
-    sim.configure(w=1, k=1, overlap=overlap)
-    sim.set_data(part); sim.update(3, 0.01); outs.append(sim.get_data()); sim.close()
-plain = nb.SimPipeline(1024, m); plain.configure(w=1, k=1); plain.set_data(part); plain.update(3, 0.01)
+    sim.configure(w=1, k=1, overlap=overlap, sharded_graph=sgraph)
+    sim.set_data(part); sim.update(3, 0.01); sim.update(3, 0.01); outs.append(sim.get_data()); sim.close()
+plain = nb.SimPipeline(1024, m); plain.configure(w=1, k=1); plain.set_data(part); plain.update(6, 0.01)
 want = plain.get_data(); plain.close()
 assert outs[0].tobytes() == want.tobytes(), "rccl 1-rank path differs"
 assert outs[1].tobytes() == want.tobytes(), "rccl 1-rank overlap path differs"
+assert outs[2].tobytes() == want.tobytes(), "rccl 1-rank captured-graph path differs"
 print("RCCL-ONE-RANK-OK")
 ''' % {"root": nb.ROOT}
     env = dict(os.environ, NB_HIP_FORCE_SHARDED="1")
