@@ -107,6 +107,9 @@ double nb_hip_last_step_ms(SimPipeline *sim, uint32_t *launches);
  *   "w"         waves (source slices) per workgroup: 0 = auto, else 1, 2, 4, 8 or 16
  *   "split"     workgroups per receiver tile, each over 1/split of the sources (a second small kernel adds
  *               the parts and integrates): 0 = auto (fills the chip / lands on a round boundary), else 1..16
+ *   "passes"    launches per step over consecutive source sub-ranges, chained through acc[]: 0 = auto (each
+ *               pass's sources fit one XCD's L2, so they are fetched once per pass instead of once per round:
+ *               23x less memory-side traffic at N = 2^20, same speed), else 1..64
  *   "graph"     1 = run step chains as hipGraphs (default), 0 = plain stream launches
  *   "sharded_graph"  sharded pipelines: 1 = capture the {kernel, all-gather} x n chain into a hipGraph and replay
  *               it (non-overlapped step only); 0 = plain stream launches (default)

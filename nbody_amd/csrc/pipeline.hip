@@ -151,6 +151,7 @@ uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
 struct StepGraph {
     uint32_t n = 0;           // steps in the chain
+    uint32_t passes = 1;      // source passes per step
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     std::vector<hipGraphNode_t> nodes;  // one kernel node per launch, in order
@@ -205,6 +206,7 @@ struct SimPipeline {
     // knobs
     int want_variant = nb::VARIANT_SMEM, want_k = 0, want_w = 0, want_split = 0;  // SMEM measures 2.5 % faster than LDS tiles
     int use_graph = 1, overlap = 0, sharded_graph = 0;
+    int want_passes = 0;  // source passes per step (0 = auto: keep each pass's sources within one XCD's L2)
     nb::LaunchShape last_shape = {0, 0, 0, 0};
     uint32_t last_groups = 0;
 
@@ -355,16 +357,50 @@ nb::StepParams shaped(const SimPipeline *s, nb::StepParams p, nb::LaunchShape sh
     return p;
 }
 
+// Source passes: a step over sources [0, n) can run as P launches over consecutive sub-ranges chained through
+// acc[] (STEP_NO_FINALIZE / STEP_ACC_IN).  All workgroups of a pass then stream the same <= ~3 MB of sources, which
+// stay resident in each XCD's 4 MiB L2 across the pass's rounds instead of being re-fetched every round.
+constexpr size_t L2_SOURCE_BUDGET = 3u << 20;  // bytes of (x, y, G*m) per pass
+
+uint32_t passes_for(const SimPipeline *s, const nb::StepParams &p) {
+    if (p.flags != 0 || p.src_end[1] != p.src_begin[1]) return 1;  // only whole, unchained steps are cut up
+    const uint32_t n = p.src_end[0] - p.src_begin[0];
+    uint32_t want = (uint32_t)s->want_passes;
+    if (want == 0) want = (uint32_t)(((size_t)n * 12 + L2_SOURCE_BUDGET - 1) / L2_SOURCE_BUDGET);
+    const uint32_t chunks = (n + 63) / 64;
+    if (want > chunks) want = chunks;
+    return want ? want : 1;
+}
+
+// The launches of one step: P passes, each = step kernel (+ finish kernel when the shape is split).
+std::vector<nb::StepParams> step_passes(const SimPipeline *s, const nb::StepParams &whole, nb::LaunchShape sh) {
+    std::vector<nb::StepParams> out;
+    const uint32_t P = passes_for(s, whole);
+    const uint32_t lo = whole.src_begin[0], n = whole.src_end[0] - lo;
+    const uint32_t per = ((n + 63) / 64 + P - 1) / P * 64;  // whole 64-source chunks per pass
+    for (uint32_t q = 0; q < P; q++) {
+        nb::StepParams p = shaped(s, whole, sh);
+        if (P > 1) {
+            p.src_begin[0] = lo + (q * per < n ? q * per : n);
+            p.src_end[0] = lo + ((q + 1) * per < n ? (q + 1) * per : n);
+            p.flags = (q > 0 ? nb::STEP_ACC_IN : 0u) | (q + 1 < P ? nb::STEP_NO_FINALIZE : 0u);
+        }
+        out.push_back(p);
+    }
+    return out;
+}
+
 void launch_step(SimPipeline *s, nb::LaunchShape sh, const nb::StepParams &p, hipStream_t st) {
     if (s->n_real == 0) return;  // a rank without receivers still takes part in the gathers
-    nb::StepParams copy = shaped(s, p, sh);
-    void *args[] = {&copy};
-    ASSERT_HIP(hipLaunchKernel(nb::step_kernel_fn(sh), nb::step_grid(sh, s->n_real), nb::step_block(sh), args, 0, st),
-               "step kernel launch (k=%d w=%d variant=%d split=%d, %u receivers)", sh.k, sh.w, sh.variant, sh.split,
-               s->n_real);
-    if (copy.split > 1)
-        ASSERT_HIP(hipLaunchKernel(nb::finish_kernel_fn(), nb::finish_grid(s->n_real), nb::finish_block(), args, 0, st),
-                   "finish kernel launch (%u receivers, %u parts)", s->n_real, copy.split);
+    for (nb::StepParams &copy : step_passes(s, p, sh)) {
+        void *args[] = {&copy};
+        ASSERT_HIP(hipLaunchKernel(nb::step_kernel_fn(sh), nb::step_grid(sh, s->n_real), nb::step_block(sh), args, 0, st),
+                   "step kernel launch (k=%d w=%d variant=%d split=%d, %u receivers)", sh.k, sh.w, sh.variant, sh.split,
+                   s->n_real);
+        if (copy.split > 1)
+            ASSERT_HIP(hipLaunchKernel(nb::finish_kernel_fn(), nb::finish_grid(s->n_real), nb::finish_block(), args, 0, st),
+                       "finish kernel launch (%u receivers, %u parts)", s->n_real, copy.split);
+    }
 }
 
 // ---- single-device chains ------------------------------------------------------------------------------------
@@ -380,20 +416,24 @@ void fill_node(hipKernelNodeParams &kp, void **args, const void *fn, dim3 grid, 
 }
 
 StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchShape sh) {
+    const uint32_t passes = passes_for(s, whole_step(s, s->cur, dt));
     StepGraph *g = nullptr;
     for (auto &c : s->graphs)
-        if (c.n == n && c.shape.k == sh.k && c.shape.w == sh.w && c.shape.variant == sh.variant && c.shape.split == sh.split)
+        if (c.n == n && c.passes == passes && c.shape.k == sh.k && c.shape.w == sh.w && c.shape.variant == sh.variant &&
+            c.shape.split == sh.split)
             g = &c;
-    const uint32_t per_step = sh.split > 1 ? 2 : 1;  // step kernel (+ finish kernel)
+    const uint32_t per_pass = sh.split > 1 ? 2 : 1;  // step kernel (+ finish kernel)
+    const uint32_t per_step = passes * per_pass;
     const bool fresh = g == nullptr;
     if (fresh) {
         s->graphs.emplace_back();
         g = &s->graphs.back();
         g->n = n;
+        g->passes = passes;
         g->shape = sh;
         ASSERT_HIP(hipGraphCreate(&g->graph, 0), "hipGraphCreate");
         g->nodes.resize((size_t)n * per_step);
-        g->params.resize(n);
+        g->params.resize((size_t)n * passes);
     } else if (g->phase == s->cur && g->dt == dt) {
         return g;
     }
@@ -401,21 +441,24 @@ StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchS
     // changes (sim_gpu.c:268-284) -- patch the instantiated graph when dt or the ping-pong phase moved
     hipGraphNode_t prev = nullptr;
     for (uint32_t i = 0; i < n; i++) {
-        g->params[i] = shaped(s, whole_step(s, (s->cur + i) & 1, dt), sh);
-        void *args[] = {&g->params[i]};
-        for (uint32_t j = 0; j < per_step; j++) {
-            hipKernelNodeParams kp;
-            if (j == 0)
-                fill_node(kp, args, nb::step_kernel_fn(sh), nb::step_grid(sh, s->n_real), nb::step_block(sh));
-            else
-                fill_node(kp, args, nb::finish_kernel_fn(), nb::finish_grid(s->n_real), nb::finish_block());
-            hipGraphNode_t &node = g->nodes[(size_t)i * per_step + j];
-            if (fresh) {
-                ASSERT_HIP(hipGraphAddKernelNode(&node, g->graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp),
-                           "hipGraphAddKernelNode step %u/%u", i, n);
-                prev = node;
-            } else {
-                ASSERT_HIP(hipGraphExecKernelNodeSetParams(g->exec, node, &kp), "hipGraphExecKernelNodeSetParams");
+        const std::vector<nb::StepParams> launches = step_passes(s, whole_step(s, (s->cur + i) & 1, dt), sh);
+        for (uint32_t q = 0; q < passes; q++) {
+            g->params[(size_t)i * passes + q] = launches[q];
+            void *args[] = {&g->params[(size_t)i * passes + q]};
+            for (uint32_t j = 0; j < per_pass; j++) {
+                hipKernelNodeParams kp;
+                if (j == 0)
+                    fill_node(kp, args, nb::step_kernel_fn(sh), nb::step_grid(sh, s->n_real), nb::step_block(sh));
+                else
+                    fill_node(kp, args, nb::finish_kernel_fn(), nb::finish_grid(s->n_real), nb::finish_block());
+                hipGraphNode_t &node = g->nodes[(size_t)i * per_step + q * per_pass + j];
+                if (fresh) {
+                    ASSERT_HIP(hipGraphAddKernelNode(&node, g->graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp),
+                               "hipGraphAddKernelNode step %u/%u", i, n);
+                    prev = node;
+                } else {
+                    ASSERT_HIP(hipGraphExecKernelNodeSetParams(g->exec, node, &kp), "hipGraphExecKernelNodeSetParams");
+                }
             }
         }
     }
@@ -553,7 +596,7 @@ void enqueue_steps(SimPipeline *s, uint32_t n, float dt) {
         enqueue_sharded(s, n, dt);
     ASSERT_HIP(hipEventRecord(s->ev_end, s->stream), "record end");
     s->timed = true;
-    s->timed_launches = (s->sharded && s->overlap) ? 2 * n : n;
+    s->timed_launches = (s->sharded && s->overlap) ? 2 * n : n * passes_for(s, whole_step(s, s->cur, dt));
     s->data.dt = dt;
 }
 
@@ -655,6 +698,8 @@ SimPipeline *CreateSimPipeline(WorldData data) {
     if (k) s->want_k = atoi(k);
     const char *w = getenv("NB_HIP_W");
     if (w) s->want_w = atoi(w);
+    const char *ps = getenv("NB_HIP_PASSES");
+    if (ps) s->want_passes = atoi(ps);
     const char *sp = getenv("NB_HIP_SPLIT");
     if (sp) s->want_split = atoi(sp);
     const char *gr = getenv("NB_HIP_GRAPH");
@@ -884,6 +929,10 @@ int nb_hip_configure(SimPipeline *s, const char *key, int value) {
     } else if (!strcmp(key, "graph")) {
         old = s->use_graph;
         s->use_graph = value ? 1 : 0;
+    } else if (!strcmp(key, "passes")) {
+        NB_ASSERT(value >= 0 && value <= 64, "passes must be 0 (auto) .. 64, got %d", value);
+        old = s->want_passes;
+        s->want_passes = value;
     } else if (!strcmp(key, "sharded_graph")) {
         old = s->sharded_graph;
         s->sharded_graph = value ? 1 : 0;
