@@ -97,19 +97,23 @@ struct Receivers {
 // variants with and without extra s_nop all pass the parity checks; fewer is faster).  Each interaction is a serial
 // dependency chain on purpose: with 8 waves per SIMD the other waves fill the gaps, and interleaved or
 // software-pipelined orders measured slower (profiles/r01_ubench3_hand_scheduled_bodies.txt).
-// The statement is pure (no memory, not volatile); 13 instructions, 56 bytes.
+// The statement is pure (no memory, not volatile); 11 instructions, 56 bytes.  The same instructions in their
+// 8-byte VOP3 encodings (76 bytes) run 11.6 % slower, so the short encodings the assembler picks matter.
+// Temporaries (clobbered): d = v[30:31], t = v32, q = v33, u = v[36:37].  Which registers matters a little
+// (VGPR banks): this assignment measured 2 % faster than q = v32, t = v33, u = v[34:35].
 #define NB_INTERACTION_ASM                                                      \
     "v_pk_add_f32 v[30:31], %[s], %[p] neg_lo:[0,1] neg_hi:[0,1]\n\t"          \
-    "v_fma_f32 v32, v30, v30, %[r]\n\t"                                        \
-    "v_fmac_f32 v32, v31, v31\n\t"                                             \
+    "v_fma_f32 v33, v30, v30, %[r]\n\t"                                        \
+    "v_fmac_f32 v33, v31, v31\n\t"                                             \
     "s_setprio 3\n\t"                                                          \
-    "v_rsq_f32 v32, v32\n\t"                                                   \
+    "v_rsq_f32 v33, v33\n\t"                                                   \
     "s_setprio 0\n\t"                                                          \
     "s_nop 0\n\t"                                                              \
-    "v_mul_f32 v33, v32, v32\n\t"                                              \
-    "v_mul_f32 v34, %[g], v32\n\t"                                             \
-    "v_mul_f32 v34, v34, v33\n\t"                                              \
-    "v_pk_fma_f32 %[a], v[30:31], v[34:35], %[a] op_sel_hi:[1,0,1]"
+    "v_mul_f32 v32, v33, v33\n\t"                                              \
+    "v_mul_f32 v36, %[g], v33\n\t"                                             \
+    "v_mul_f32 v36, v36, v32\n\t"                                              \
+    "v_pk_fma_f32 %[a], v[30:31], v[36:37], %[a] op_sel_hi:[1,0,1]"
+#define NB_CLOBBERS "v30", "v31", "v32", "v33", "v36", "v37"
 
 // SRC_IN_SGPR: the source sits in SGPRs (scalar-cache route) or in VGPRs holding a wave-uniform value
 // (LDS broadcast reads); the instructions are the same, only the operand class differs.
@@ -117,17 +121,16 @@ template <int K, bool SRC_IN_SGPR>
 __device__ __forceinline__ void interact(Receivers<K> &R, f2v sxy, float sg) {
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        // temporaries live in fixed registers (clobbered): d = v[30:31], q = v32, t = v33, u = v[34:35]
         if constexpr (SRC_IN_SGPR) {
             asm(NB_INTERACTION_ASM
                 : [a] "+v"(R.a[k])
                 : [s] "s"(sxy), [g] "s"(sg), [p] "v"(R.p[k]), [r] "v"(R.r[k])
-                : "v30", "v31", "v32", "v33", "v34", "v35");
+                : NB_CLOBBERS);
         } else {
             asm(NB_INTERACTION_ASM
                 : [a] "+v"(R.a[k])
                 : [s] "v"(sxy), [g] "v"(sg), [p] "v"(R.p[k]), [r] "v"(R.r[k])
-                : "v30", "v31", "v32", "v33", "v34", "v35");
+                : NB_CLOBBERS);
         }
     }
 }
