@@ -99,8 +99,8 @@ struct Receivers {
 // software-pipelined orders measured slower (profiles/r01_ubench3_hand_scheduled_bodies.txt).
 // The statement is pure (no memory, not volatile); 11 instructions, 56 bytes.  The same instructions in their
 // 8-byte VOP3 encodings (76 bytes) run 11.6 % slower, so the short encodings the assembler picks matter.
-// Temporaries (clobbered): d = v[30:31], t = v32, q = v33, u = v[36:37].  Which registers matters a little
-// (VGPR banks): this assignment measured 2 % faster than q = v32, t = v33, u = v[34:35].
+// Temporaries (clobbered): d = v[30:31], t = v32, q = v33, u = v[36:37].  Ten other assignments measured the
+// same within the 1-2 % box-to-box spread.
 #define NB_INTERACTION_ASM                                                      \
     "v_pk_add_f32 v[30:31], %[s], %[p] neg_lo:[0,1] neg_hi:[0,1]\n\t"          \
     "v_fma_f32 v33, v30, v30, %[r]\n\t"                                        \
