@@ -91,14 +91,18 @@ struct Receivers {
 // (profiles/r01_sweep_auto_split.txt, r01_sweep8_full_asm_nops_alignment.txt).  One fixed sequence on six fixed
 // temporaries cannot drift: 36 VGPRs, 108-110 ms.  (2) A v_rsq_f32 that lands between other waves' plain VALU
 // instructions costs ~16 cycles instead of 8 on gfx950; raising the wave priority for just that instruction buys
-// 2 % here (profiles/r01_ubench5_setprio_rsq.txt).  (3) gfx950 needs a wait state between a transcendental and
-// the VALU instruction that reads its result, and hipcc cannot pad inside asm: the s_nop after the rsq is ours.
-// The other dependent pairs are ordinary VALU read-after-write, which the hardware interlocks (measured: the
-// variants with and without extra s_nop all pass the parity checks; fewer is faster).  Each interaction is a serial
+// 6 % here (profiles/r01_ubench5_setprio_rsq.txt, r01_sweep9_nops_and_static_priority.txt; static per-wave
+// priorities instead are 3x SLOWER).  (3) gfx950 needs one wait state between a transcendental and the VALU
+// instruction that reads its result, and hipcc cannot pad inside asm: the s_setprio 0 that follows the rsq IS that
+// wait state (an earlier version with nothing in between read stale values; the parity tests caught it).  An
+// extra s_nop there costs 2.3 %.  The other dependent pairs are ordinary VALU read-after-write, which the
+// hardware interlocks.  (4) One statement per interaction, not one per 8 sources: hipcc pads each asm boundary with
+// an s_nop, which makes the body 52 + 4 = 56 bytes; the same 52-byte body back to back with no filler at all runs
+// 8 % slower (instruction-stream phase), see the second table of r01_sweep9.  Each interaction is a serial
 // dependency chain on purpose: with 8 waves per SIMD the other waves fill the gaps, and interleaved or
 // software-pipelined orders measured slower (profiles/r01_ubench3_hand_scheduled_bodies.txt).
-// The statement is pure (no memory, not volatile); 11 instructions, 56 bytes.  The same instructions in their
-// 8-byte VOP3 encodings (76 bytes) run 11.6 % slower, so the short encodings the assembler picks matter.
+// The statement is pure (no memory, not volatile); 10 instructions, 52 bytes.  The same instructions in their
+// 8-byte VOP3 encodings (72 bytes) run 11.6 % slower, so the short encodings the assembler picks matter.
 // Temporaries (clobbered): d = v[30:31], t = v32, q = v33, u = v[36:37].  Ten other assignments measured the
 // same within the 1-2 % box-to-box spread.
 #define NB_INTERACTION_ASM                                                      \
@@ -108,7 +112,6 @@ struct Receivers {
     "s_setprio 3\n\t"                                                          \
     "v_rsq_f32 v33, v33\n\t"                                                   \
     "s_setprio 0\n\t"                                                          \
-    "s_nop 0\n\t"                                                              \
     "v_mul_f32 v32, v33, v33\n\t"                                              \
     "v_mul_f32 v36, %[g], v33\n\t"                                             \
     "v_mul_f32 v36, v36, v32\n\t"                                              \
