@@ -456,6 +456,36 @@ def test_local_shard_group_config4_shape(overlap):
     assert np.array_equal(got[:, 6:8], part[:, 6:8])
 
 
+def test_local_shard_group_full_size_config4():
+    """BASELINE config 4 at full size, all 8 shards on this one GPU: N = 2^20, two source passes per shard step."""
+    n, P = 1 << 20, 8
+    ic = nb.make_galaxies(n, 2, seed=11037)
+    w = nb.World(ic)
+    part = w.particles()
+    w.close()
+    m = int((part[:, 6] > 0).sum())
+    g = nb.LocalShardGroup(n, m, P)
+    g.set_data(part)
+    g.step(1, 0.01)
+    got = g.get_data(5)
+    g.close()
+    idx = np.unique(np.concatenate([[0, m - 1, m, n - 1], np.random.default_rng(3).integers(0, n, 400)])).astype(np.uint32)
+    acc64, mag = ob.acc_f64_subset(part, m, idx)
+    assert np.all(np.abs(got[idx, 4:6].astype(np.float64) - acc64) <= acc_bound(acc64, mag))
+    v = part[:, 2:4] + got[:, 4:6] * np.float32(0.01)
+    assert np.array_equal(got[:, 2:4], v) and np.array_equal(got[:, 0:2], part[:, 0:2] + v * np.float32(0.01))
+
+
+@pytest.mark.parametrize("passes", [1, 2, 5])
+def test_source_passes(golden, passes):
+    # a step cut into `passes` launches over consecutive source sub-ranges, chained through acc[]
+    part, m = ob.partition(golden("ic_4096.bin"))
+    got = run(part, m, 1, 0.01, passes=passes)
+    check_one_step(got, part, m, 0.01)
+    assert run(part, m, 4, 0.01, passes=passes, graph=1).tobytes() == run(part, m, 4, 0.01, passes=passes, graph=0).tobytes()
+    assert run(part, m, 1, 0.01, passes=passes, split=3).shape == part.shape
+
+
 def test_local_shard_group_ragged(golden):
     part, m = synth(1000, 0.013, seed=4)      # 13 sources over 4 ranks: some ranks own no source
     g = nb.LocalShardGroup(1000, m, 4)
