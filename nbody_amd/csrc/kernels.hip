@@ -192,11 +192,12 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
     finish_receiver(p, logical, sx, sy);
 }
 
-// K <= 2 must stay within 64 VGPRs: a 1024-thread workgroup puts 4 waves on every SIMD, so 65 VGPRs (7 waves per
-// SIMD) would mean ONE resident workgroup per CU instead of two.  The asm body needs 36 (SMEM) / 62 (LDS); the
-// second launch-bound argument (waves per SIMD) makes the limit explicit.
+// Everything must stay within 64 VGPRs: a 1024-thread workgroup puts 4 waves on every SIMD, so 65 VGPRs (7 waves
+// per SIMD) would mean ONE resident workgroup per CU instead of two.  The asm body needs 36 (SMEM, K <= 2) / 62 (LDS);
+// the second launch-bound argument (waves per SIMD) makes the limit explicit.  K = 4 then keeps its Kahan state in
+// scratch, touched only at block closes outside the inner loop, and runs as fast as K = 2.
 template <int K, int W, int VARIANT>
-__global__ __launch_bounds__(WAVE *W, (K <= 2 ? 8 : 4)) void step_kernel(const StepParams p) {
+__global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (WAVE - 1);
     // wave id as an SGPR value so that everything derived from it stays scalar
