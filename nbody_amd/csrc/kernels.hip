@@ -407,11 +407,11 @@ const void *pick(int k, int w) {
 
 LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int compute_units) {
     // Workgroups of one launch all take the same time, so a launch costs
-    //     rounds * (work per workgroup),   rounds = ceil(workgroups / resident capacity),
+    //     (rounds + tail) * (work per workgroup),   rounds = ceil(workgroups / resident capacity),
     // and one workgroup past a round boundary costs a whole round (1025 workgroups on 512 slots run 1.5x as
     // long as 1024; profiles/r01_shard_overhead_before_fix.txt).  Work per workgroup = K receivers per lane x
     // the 64-source chunks one wave walks.  Pick the cheapest (K, W, split); ties go to the larger K, larger W,
-    // smaller split (less traffic, shorter fp32 sums, no second kernel).  K = 4 is left out: 71 VGPRs, lower
+    // smaller split.  More, shorter workgroups also shrink the launch's ramp-up/ragged-end share.  K = 4 is left out: 71 VGPRs, lower
     // occupancy, never faster (profiles/r01_sweep4_shapes_by_n.txt).
     if (compute_units <= 0) compute_units = 256;
     const uint32_t chunks = (n_src + CHUNK - 1) / CHUNK;
@@ -428,11 +428,14 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
                 const uint64_t rounds = (groups + capacity - 1) / capacity;
                 const uint32_t part_chunks = (chunks + sp - 1) / sp;
                 const uint32_t wave_chunks = (part_chunks + w - 1) / w;
-                // + 1 chunk-equivalent per workgroup round for prologue/epilogue, + a little for the finish kernel
-                double cost = (double)rounds * ((double)k * (wave_chunks ? wave_chunks : 1) + 1.0);
-                if (sp > 1) cost = cost * 1.03 + 2.0 + 0.05 * sp;  // a split has to pay for itself clearly
+                // + 1 chunk-equivalent per workgroup for prologue/epilogue; + TAIL rounds per launch for ramp-up and
+                // the ragged end (measured: 2-round launches run 4.5 % over, 16-round ones 0.1 % over:
+                // profiles/r01_shard_overhead_split.txt); a split adds the finish kernel and the parts traffic
+                constexpr double TAIL = 0.13;
+                double cost = ((double)rounds + TAIL) * ((double)k * (wave_chunks ? wave_chunks : 1) + 1.0);
+                if (sp > 1) cost += 3.0 + 0.02 * sp;
                 if (w < 16) cost *= 1.01;
-                if (k == 1) cost *= 1.25;  // measured: hipcc serialises the K = 1 body (profiles/r01_sweep_auto_split.txt)
+                if (k == 1) cost *= 1.25;  // measured: K = 1 is slower per interaction at large N
                 if (best_cost < 0.0 || cost < best_cost * 0.999) {
                     best_cost = cost;
                     best.k = k;

@@ -298,11 +298,18 @@ void materialize(SimPipeline *s) {
     s->on_device = true;
 }
 
+uint32_t passes_for(const SimPipeline *s, const nb::StepParams &p);
+
 nb::LaunchShape resolve_shape(SimPipeline *s) {
     // the overlapped sharded step chains two launches through acc[]: keep those unsplit
     const int split = (s->sharded && s->overlap) ? 1 : s->want_split;
     nb::LaunchShape want = {s->want_k, s->want_w, s->want_variant, split};
-    nb::LaunchShape sh = nb::choose_shape(want, s->n_real, s->n_src, g_dev.compute_units);
+    // the model sees one launch: with source passes that is 1/passes of the sources
+    nb::StepParams probe;
+    memset(&probe, 0, sizeof probe);
+    probe.src_end[0] = s->n_src;
+    const uint32_t passes = (s->sharded && s->overlap) ? 1 : passes_for(s, probe);
+    nb::LaunchShape sh = nb::choose_shape(want, s->n_real, (s->n_src + passes - 1) / passes, g_dev.compute_units);
     NB_ASSERT(nb::step_kernel_fn(sh) != nullptr, "no step kernel for k=%d w=%d variant=%d", sh.k, sh.w, sh.variant);
     if (sh.split > 1) {
         const size_t need = (size_t)sh.split * s->n_real;

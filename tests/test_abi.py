@@ -120,13 +120,17 @@ def test_shard_plan_bench_case_lands_on_round_boundaries():
 
 
 def test_launch_plan_round_boundaries_and_splits():
-    # 256 CUs, two 1024-thread workgroups resident per CU = 512 slots
-    for n, m in ((1 << 20, 523884), (262144, 130916), (65536, 32641), (131072, 524288)):
+    # 256 CUs, two 1024-thread workgroups resident per CU = 512 slots per round
+    for n, m in ((1 << 20, 523884), (262144, 130916), (65536, 32641), (131072, 262144)):
         p = nb.plan_launch(n, m)
-        assert (p["k"], p["w"], p["split"]) == (2, 16, 1) and p["workgroups"] == n // 128   # whole rounds: unsplit
+        # large grids: K = 2, W = 16, whole rounds; a modest split keeps the launch's ragged end small
+        assert (p["k"], p["w"]) == (2, 16) and 1 <= p["split"] <= 8
+        assert p["workgroups"] == n // 128 * p["split"] and p["workgroups"] % 512 == 0
     for n, m in ((100000, 49944), (20000, 9956), (200000, 99899)):
         p = nb.plan_launch(n, m)
         assert p["split"] > 1 and p["workgroups"] == -(-n // (64 * p["k"])) * p["split"]    # off a boundary: split
+        rounds = -(-p["workgroups"] // (256 * 32 // p["w"]))
+        assert p["workgroups"] / (rounds * 256 * 32 // p["w"]) > 0.9                          # last round nearly full
     for n, m in ((250, 119), (1000, 485), (4096, 1989)):
         p = nb.plan_launch(n, m)
         assert p["k"] == 1 and p["split"] == 1                                              # launch-bound: simplest
