@@ -301,9 +301,7 @@ void materialize(SimPipeline *s) {
 uint32_t passes_for(const SimPipeline *s, const nb::StepParams &p);
 
 nb::LaunchShape resolve_shape(SimPipeline *s) {
-    // the overlapped sharded step chains two launches through acc[]: keep those unsplit
-    const int split = (s->sharded && s->overlap) ? 1 : s->want_split;
-    nb::LaunchShape want = {s->want_k, s->want_w, s->want_variant, split};
+    nb::LaunchShape want = {s->want_k, s->want_w, s->want_variant, s->want_split};
     // the model sees one launch: with source passes that is 1/passes of the sources
     nb::StepParams probe;
     memset(&probe, 0, sizeof probe);
