@@ -101,6 +101,15 @@ void nb_hip_sync(SimPipeline *sim);
 double nb_hip_last_step_ms(SimPipeline *sim, uint32_t *launches);
 
 /*
+ * Optional: tell the pipeline which long-lived host array Set/GetSimulationData will be called with (the World's
+ * particle array).  It is page-locked (hipHostRegister) when the pipeline first touches the GPU and released in
+ * DestroySimPipeline, so the hand-over runs at PCIe speed instead of through pageable memory.  The array must stay
+ * allocated until DestroySimPipeline or until this is called again (array = NULL forgets it).  Set/Get with any
+ * other pointer keep working unchanged.
+ */
+void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
+
+/*
  * Tuning knobs.  key is one of:
  *   "variant"   0 = wave-private LDS tiles, 1 = scalar-cache (SMEM) source broadcast (default: measured 2.5 % faster)
  *   "k"         receivers per lane: 0 = auto, else 1, 2 or 4

@@ -47,6 +47,7 @@ HIP_API = {
     "nb_hip_step_async": (None, [C.c_void_p, C.c_uint32, C.c_float]),
     "nb_hip_sync": (None, [C.c_void_p]),
     "nb_hip_last_step_ms": (C.c_double, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "nb_hip_note_host_array": (None, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "nb_hip_configure": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "nb_hip_launch_shape": (None, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),

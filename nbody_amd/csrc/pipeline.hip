@@ -192,6 +192,9 @@ struct SimPipeline {
     float *src_gm = nullptr;
     void *aos = nullptr;     // device AoS staging for Set/Get (whole world)
     void *aos_shard = nullptr;  // sharded only: this rank's slice, uniform size
+    void *host_array = nullptr;  // caller's long-lived particle array (nb_hip_note_host_array), page-locked lazily
+    size_t host_bytes = 0;
+    bool host_pinned = false;
     float2 *parts = nullptr;    // split steps only: [split][n_real] partial sums
     uint32_t parts_cap = 0;     // float2 elements allocated in parts
     int cur = 0;             // pos[cur] is the latest state
@@ -226,9 +229,27 @@ void destroy_graph(StepGraph &g) {
     g.params.clear();
 }
 
+void unpin_host(SimPipeline *s) {
+    if (s->host_pinned) {
+        // best effort: the array is the caller's; failing to unregister must not take the process down
+        (void)hipHostUnregister(s->host_array);
+        s->host_pinned = false;
+    }
+}
+
+void pin_host(SimPipeline *s) {
+    if (s->host_pinned || s->host_array == nullptr || s->host_bytes == 0) return;
+    // page-lock the caller's array so that H2D / D2H run at PCIe speed instead of through a pageable bounce
+    if (hipHostRegister(s->host_array, s->host_bytes, hipHostRegisterDefault) == hipSuccess)
+        s->host_pinned = true;
+    else
+        (void)hipGetLastError();  // not fatal: copies stay correct, only slower
+}
+
 void release_device(SimPipeline *s) {
     if (!s->on_device) return;
     ASSERT_HIP(hipStreamSynchronize(s->stream), "sync before release");
+    unpin_host(s);
     for (auto &g : s->graphs) destroy_graph(g);
     s->graphs.clear();
     for (int b = 0; b < 2; b++) {
@@ -296,6 +317,7 @@ void materialize(SimPipeline *s) {
         s->aos_shard = dev_alloc<Particle>((size_t)s->slots * (size_t)s->nranks);
     }
     s->on_device = true;
+    pin_host(s);
 }
 
 uint32_t passes_for(const SimPipeline *s, const nb::StepParams &p);
@@ -909,6 +931,15 @@ double nb_hip_last_step_ms(SimPipeline *s, uint32_t *launches) {
     ASSERT_HIP(hipEventElapsedTime(&ms, s->ev_begin, s->ev_end), "hipEventElapsedTime");
     if (launches) *launches = s->timed_launches;
     return (double)ms;
+}
+
+void nb_hip_note_host_array(SimPipeline *s, void *array, uint64_t bytes) {
+    NB_ASSERT(s != nullptr, "NULL pipeline");
+    if (s->on_device) ASSERT_HIP(hipStreamSynchronize(s->stream), "sync before re-registering the host array");
+    unpin_host(s);
+    s->host_array = array;
+    s->host_bytes = (size_t)bytes;
+    if (s->on_device) pin_host(s);
 }
 
 int nb_hip_configure(SimPipeline *s, const char *key, int value) {

@@ -66,6 +66,9 @@ World *CreateWorld(const Particle *ps, uint32_t size) {
     w->count = size;
     w->massive = partition_by_mass(w->particles, size);
     w->gpu = CreateSimPipeline((WorldData){.total_len = size, .mass_len = w->massive, .dt = 0.0f});
+    /* this array is what every later Set/GetSimulationData moves: let the pipeline page-lock it when (if) it
+     * first touches the GPU.  DestroyWorld destroys the pipeline before freeing the array. */
+    nb_hip_note_host_array(w->gpu, w->particles, (uint64_t)size * sizeof(Particle));
     w->cpu = CpuSimCreate(w->massive);
     w->host_is_newer = true;    /* the device has seen nothing yet */
     w->device_is_newer = false;
