@@ -35,11 +35,16 @@ N_PARTICLES = 1 << 20
 DT = 0.01
 
 
-def make_workload(n):
+def make_workload(n, all_massive=False):
     """Product code only: MakeGalaxies + CreateWorld's partition (no GPU touched)."""
     import nbody_amd as nb
 
     ic = nb.make_galaxies(n, 2, seed=11037)
+    if all_massive:
+        # SURVEY.md 8d: the N^2 run of the N-body literature.  The massless half gets the mass galaxy.h would
+        # give a body of its radius (NP_R_TO_M(0.5) = 4*pi*10/3 * 0.125), so every particle is a source.
+        light = ic[:, 6] <= 0
+        ic[light, 6] = np.float32(4.0 * np.pi * 10.0 / 3.0) * ic[light, 7] ** 3
     w = nb.World(ic)
     part = w.particles()
     w.close()
@@ -122,6 +127,8 @@ def main():
     ap.add_argument("--particles", dest="n", type=int, default=N_PARTICLES,
                     help="particles (default 2^20, the size the metric is quoted on); not --n: torchrun claims that prefix")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--all-massive", action="store_true",
+                    help="informational N^2 run: every particle is a source (not the BASELINE.json workload)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse the multi-rank control flow (rendezvous, id broadcast, barriers, reduction, JSON) "
                          "without touching a GPU: no step runs and the reported value is 0")
@@ -157,7 +164,7 @@ def main():
     if not args.dry_run:
         ndev = nb.device_count()
         nb.hip_lib().nb_hip_set_device(local_rank if local_rank < max(ndev, 1) else local_rank % max(ndev, 1))
-    part, mass_len = make_workload(args.n)
+    part, mass_len = make_workload(args.n, args.all_massive)
     n = part.shape[0]
 
     uid = None
@@ -231,7 +238,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"srand(11037) MakeGalaxies({n}, 2) (galaxy.h ICs), partitioned; N={n}, mass_len={mass_len}, "
+                "workload": f"srand(11037) MakeGalaxies({n}, 2) (galaxy.h ICs)"
+                            f"{', massless half given NP_R_TO_M(radius) mass (all-massive N^2 run)' if args.all_massive else ''}"
+                            f", partitioned; N={n}, mass_len={mass_len}, "
                             f"dt={DT}; {n * mass_len:.4g} interactions/step; one PerformSimUpdate({args.steps}) call",
                 "parallelism": f"receivers sharded N/{world} per GPU, all-gather of source positions per step"
                                if world > 1 else "single GPU",
@@ -244,7 +253,7 @@ def main():
                 "peak": PEAK_FP32_VECTOR_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved_tflops / PEAK_FP32_VECTOR_TFLOPS,
-                "traffic": pmc_traffic(),
+                "traffic": None if args.all_massive else pmc_traffic(),
                 "flop_per_interaction": FLOP_PER_INTERACTION,
                 "kernel_ms_per_launch": per_launch_s * 1e3,
                 "launches": launches,

@@ -65,6 +65,16 @@ extern "C" {
  */
 Particle *MakeGalaxies(uint32_t particle_count, uint32_t galaxy_count);
 
+/*
+ * Extension (not in the reference): the same generator drawing from a built-in
+ * xoshiro256** stream seeded with `seed` instead of libc rand(), so that one
+ * (particle_count, galaxy_count, seed) names the same draws on any libc.  Does
+ * not touch the rand() state.  (The particle formulas still call libm's sqrtf,
+ * cosf, sinf and hypotf; a libm that rounds those differently moves a particle
+ * by an ulp, not the universe.)
+ */
+Particle *MakeGalaxiesSeeded(uint32_t particle_count, uint32_t galaxy_count, uint64_t seed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,7 @@ NBODY_API = {
     "UpdateWorld_CPU": (None, [C.c_void_p, C.c_float, C.c_uint32]),
     "UpdateWorld_GPU": (None, [C.c_void_p, C.c_float, C.c_uint32]),
     "MakeGalaxies": (C.c_void_p, [C.c_uint32, C.c_uint32]),
+    "MakeGalaxiesSeeded": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_uint64]),
 }
 
 _hip = None
@@ -280,14 +281,18 @@ class World:
         nbody_lib().UpdateWorld_GPU(self._h, dt, n)
 
 
-def make_galaxies(particle_count, galaxy_count, seed=None):
-    """include/galaxy.h MakeGalaxies; `seed` calls libc srand first (bench.c:42 uses 11037)."""
+def make_galaxies(particle_count, galaxy_count, seed=None, own_rng=False):
+    """include/galaxy.h MakeGalaxies; `seed` calls libc srand first (bench.c:42 uses 11037).
+    own_rng=True: MakeGalaxiesSeeded, the libc-independent stream (seed required)."""
     L = nbody_lib()
     libc = C.CDLL(None)
     libc.free.argtypes = [C.c_void_p]
-    if seed is not None:
-        libc.srand(C.c_uint(seed))
-    p = L.MakeGalaxies(particle_count, galaxy_count)
+    if own_rng:
+        p = L.MakeGalaxiesSeeded(particle_count, galaxy_count, int(seed))
+    else:
+        if seed is not None:
+            libc.srand(C.c_uint(seed))
+        p = L.MakeGalaxies(particle_count, galaxy_count)
     a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(particle_count, 8)).copy()
     libc.free(p)
     return a

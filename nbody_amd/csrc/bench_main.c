@@ -14,6 +14,7 @@
  *   --dt DT        step size              (default 1.0, the reference's)
  *   --galaxies G   galaxies per universe  (default 2)
  *   --seed S       srand seed             (default 11037)
+ *   --own-rng      draw the universes from MakeGalaxiesSeeded(seed + row) instead of libc rand()
  * and two more columns: interactions/s = N * mass_len * steps / time.
  */
 #include <stdbool.h>
@@ -56,6 +57,7 @@ int main(int argc, char **argv) {
     uint32_t n_sizes = 0;
     uint32_t steps = 100, warmup = 10, galaxies = 2;
     unsigned seed = 11037;
+    bool own_rng = false;
     float dt = 1.f;
 
     for (int a = 1; a < argc; a++) {
@@ -77,9 +79,12 @@ int main(int argc, char **argv) {
             galaxies = (uint32_t)strtoul(val, NULL, 0), a++;
         } else if (!strcmp(arg, "--seed") && val) {
             seed = (unsigned)strtoul(val, NULL, 0), a++;
+        } else if (!strcmp(arg, "--own-rng")) {
+            own_rng = true;
         } else {
             fprintf(stderr,
-                    "usage: %s [--cpu|--gpu] [--n N]... [--steps K] [--warmup W] [--dt DT] [--galaxies G] [--seed S]\n",
+                    "usage: %s [--cpu|--gpu] [--n N]... [--steps K] [--warmup W] [--dt DT] [--galaxies G] [--seed S]"
+                    " [--own-rng]\n",
                     argv[0]);
             return 2;
         }
@@ -101,7 +106,7 @@ int main(int argc, char **argv) {
 
     for (uint32_t s = 0; s < n_sizes; s++) {
         const uint32_t n = sizes[s];
-        Particle *ps = MakeGalaxies(n, galaxies);
+        Particle *ps = own_rng ? MakeGalaxiesSeeded(n, galaxies, seed + s) : MakeGalaxies(n, galaxies);
         const double pairs = (double)n * (double)count_massive(ps, n);
 
         double cpu_s = 0, gpu_s = 0;

@@ -29,14 +29,52 @@ typedef struct Galaxy {
     float outer;    /* nominal extent */
 } Galaxy;
 
-/* uniform float in [lo, hi): evaluated in double, one rand() (reference galaxy.c:18-20) */
-static float draw_float(double lo, double hi) { return (float)(lo + (hi - lo) * rand() / RAND_MAX); }
+/*
+ * Source of the raw 31-bit draws.  Default: libc rand(), which is what makes the output match the
+ * reference's under srand().  MakeGalaxiesSeeded swaps in a generator of our own (below) so that a
+ * universe can be regenerated on a box with a different libc; everything downstream of the draw is shared.
+ */
+static uint64_t own_state[4];
 
-/* uniform integer in [lo, hi), one rand() (reference galaxy.c:23-25) */
-static uint32_t draw_uint(uint32_t lo, uint32_t hi) { return lo + ((uint32_t)rand() % (hi - lo)); }
+static uint64_t rotl64(uint64_t v, int k) { return (v << k) | (v >> (64 - k)); }
 
-/* one rand(), low bit (reference galaxy.c:27-29) */
-static bool draw_bool(void) { return rand() & 1; }
+/* xoshiro256** (Blackman & Vigna), top 31 bits -> same range as glibc's rand(), RAND_MAX = 2^31 - 1 */
+static int own_rand(void) {
+    uint64_t *s = own_state;
+    const uint64_t out = rotl64(s[1] * 5, 7) * 9;
+    const uint64_t t = s[1] << 17;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl64(s[3], 45);
+    return (int)(out >> 33);
+}
+
+/* splitmix64 expands the seed into the four state words (never all zero) */
+static void own_seed(uint64_t seed) {
+    for (int i = 0; i < 4; i++) {
+        uint64_t z = (seed += 0x9e3779b97f4a7c15ull);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        own_state[i] = z ^ (z >> 31);
+    }
+}
+
+#define OWN_RAND_MAX 2147483647 /* glibc's RAND_MAX, so both sources cover the same range */
+
+static int (*raw_draw)(void) = rand;
+static int raw_max = RAND_MAX;
+
+/* uniform float in [lo, hi): evaluated in double, one draw (reference galaxy.c:18-20) */
+static float draw_float(double lo, double hi) { return (float)(lo + (hi - lo) * raw_draw() / raw_max); }
+
+/* uniform integer in [lo, hi), one draw (reference galaxy.c:23-25) */
+static uint32_t draw_uint(uint32_t lo, uint32_t hi) { return lo + ((uint32_t)raw_draw() % (hi - lo)); }
+
+/* one draw, low bit (reference galaxy.c:27-29) */
+static bool draw_bool(void) { return raw_draw() & 1; }
 
 static float sign_draw(void) { return draw_bool() ? -1.f : 1.f; }
 
@@ -176,5 +214,15 @@ Particle *MakeGalaxies(uint32_t particle_count, uint32_t galaxy_count) {
     for (uint32_t g = 0; g < galaxy_count; g++) fill_arms(&gs[g], out);
 
     free(gs);
+    return out;
+}
+
+Particle *MakeGalaxiesSeeded(uint32_t particle_count, uint32_t galaxy_count, uint64_t seed) {
+    own_seed(seed);
+    raw_draw = own_rand;
+    raw_max = OWN_RAND_MAX;
+    Particle *out = MakeGalaxies(particle_count, galaxy_count);
+    raw_draw = rand;
+    raw_max = RAND_MAX;
     return out;
 }

@@ -111,6 +111,33 @@ def test_make_galaxies_bit_exact_with_compiled_reference(n, g, seed):
     assert nb.make_galaxies(n, g, seed=seed).tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize("n", [4096, 1024, 333])
+def test_make_galaxies_seeded_is_pinned_and_leaves_rand_alone(manifest, n):
+    # the libc-independent stream (galaxy.h extension): same digests on every box, rand() state untouched
+    libc = C.CDLL(None)
+    libc.srand(5)
+    want_next = [libc.rand() for _ in range(3)]
+    libc.srand(5)
+    got = nb.make_galaxies(n, 2, seed=11037, own_rng=True)
+    assert [libc.rand() for _ in range(3)] == want_next
+    assert ob.sha256(got) == manifest["own_rng_digests"][str(n)]
+    assert nb.make_galaxies(n, 2, seed=11038, own_rng=True).tobytes() != got.tobytes()
+    # and the libc mode still matches the reference afterwards
+    assert ob.sha256(nb.make_galaxies(n, 2, seed=11037)) == manifest["sets"][str(n)]["ic_sha256"]
+
+
+def test_make_galaxies_seeded_has_the_galaxy_h_distributions():
+    a = nb.make_galaxies(200000, 2, seed=3, own_rng=True)
+    mass, radius = a[:, 6], a[:, 7]
+    cores = mass > 1e8
+    assert cores.sum() == 2 and (radius[cores] >= 200).all() and (radius[cores] < 600).all()   # galaxy.h:13-14
+    massless = mass <= 0
+    assert 0.48 < massless.mean() < 0.52 and (radius[massless] == 0.5).all()                    # galaxy.c:204-206
+    arms = ~cores & ~massless
+    assert (radius[arms] >= 1.5).all() and (radius[arms] < 9.5).all()                            # galaxy.h:16-17
+    assert np.isfinite(a).all()
+
+
 def test_make_galaxies_too_few_particles_aborts():
     code = "import nbody_amd as nb; nb.make_galaxies(150, 2, seed=1); print('SURVIVED')"
     r = subprocess.run(["python", "-c", code], cwd=nb.ROOT, capture_output=True, text=True)
@@ -123,6 +150,9 @@ def test_nbody_bench_cpu_table_runs():
                        capture_output=True, text=True, check=True)
     lines = [l.split() for l in r.stdout.strip().splitlines()]
     assert lines[0][:2] == ["N", "CPU"] and [l[0] for l in lines[1:]] == ["250", "500"]
+    r = subprocess.run([exe, "--cpu", "--own-rng", "--n", "250", "--steps", "2", "--warmup", "0"],
+                       capture_output=True, text=True, check=True)
+    assert r.stdout.strip().splitlines()[1].split()[0] == "250"
 
 
 @pytest.mark.skipif(not os.path.exists(ob.REF_WORLD_SO), reason="oracle/_ref not built")
