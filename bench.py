@@ -71,16 +71,34 @@ def cpu_baseline(part, mass_len, budget_s=12.0):
             kind = "reference"
         except Exception as e:  # pragma: no cover - diagnostic only
             print(f"[bench] reference CPU leg failed ({e}); using the port", file=sys.stderr)
+    one = None
     if sec is None:
         sec, threads, _ = ob.time_avx_sample(part, mass_len, 0, recv, dt=DT, threads=cores)
+    else:
+        # SURVEY.md 8d also asks for the 1-thread figure: ~2 s of the same loop on one core
+        recv1 = max(64, min(n, int(2.0 * 2.0e9 / max(mass_len, 1))))
+        one = recv1 * mass_len / _time_reference_packedupdate(ob.REF_CPU_SO, part, mass_len, recv1, 1)
     return {
         "value": recv * mass_len / sec,
         "unit": "interactions/s",
         "cores": threads,
         "kind": kind,
+        "cpu_model": _cpu_model(),
+        "value_1_thread": one,
         "sample": f"{recv} of {n} receivers x all {mass_len} sources, one step, AVX (-mavx, no FMA) + {threads} threads"
                   f" ({sec:.2f} s); whole step would take ~{sec * n / recv:.0f} s",
     }
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
 
 
 def _time_reference_packedupdate(so, part, mass_len, recv, cores):
