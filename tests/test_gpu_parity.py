@@ -476,6 +476,28 @@ def test_local_shard_group_full_size_config4():
     assert np.array_equal(got[:, 2:4], v) and np.array_equal(got[:, 0:2], part[:, 0:2] + v * np.float32(0.01))
 
 
+def test_local_shard_group_full_size_config5_overlapped():
+    """BASELINE config 5 at full size, all 8 shards on this one GPU: N = 2^22, own-slice kernel overlapped with
+    the gather, then the remote-slice kernel (several source passes each)."""
+    n, P = 1 << 22, 8
+    ic = nb.make_galaxies(n, 2, seed=11037)
+    w = nb.World(ic)
+    part = w.particles()
+    w.close()
+    m = int((part[:, 6] > 0).sum())
+    g = nb.LocalShardGroup(n, m, P, overlap=1)
+    g.set_data(part)
+    g.step(1, 0.01)
+    got = g.get_data(2)
+    g.close()
+    idx = np.unique(np.concatenate([[0, m - 1, m, n - 1], np.random.default_rng(5).integers(0, n, 200)])).astype(np.uint32)
+    acc64, mag = ob.acc_f64_subset(part, m, idx)
+    assert np.all(np.abs(got[idx, 4:6].astype(np.float64) - acc64) <= acc_bound(acc64, mag))
+    v = part[:, 2:4] + got[:, 4:6] * np.float32(0.01)
+    assert np.array_equal(got[:, 2:4], v) and np.array_equal(got[:, 0:2], part[:, 0:2] + v * np.float32(0.01))
+    assert np.array_equal(got[:, 6:8], part[:, 6:8])
+
+
 @pytest.mark.parametrize("passes", [1, 2, 5])
 def test_source_passes(golden, passes):
     # a step cut into `passes` launches over consecutive source sub-ranges, chained through acc[]
