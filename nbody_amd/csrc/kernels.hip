@@ -286,19 +286,44 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
             const uint32_t groups = (j_end - j) / 8;
             const uint32_t g0 = (a - v_lo) / 8;  // groups of this slice that lie in the previous range
             if (groups > 0) {
-                v16f P = *reinterpret_cast<const v16f *>(sp + 2 * (size_t)j);
-                v8f G = *reinterpret_cast<const v8f *>(sg + j);
-                for (uint32_t g = 0; g < groups; g++) {
-                    const v16f Pc = P;
-                    const v8f Gc = G;
-                    j += 8;
-                    if (g + 1 < groups) {  // next group's scalar-cache latency hides under this group's math
-                        P = *reinterpret_cast<const v16f *>(sp + 2 * (size_t)j);
-                        G = *reinterpret_cast<const v8f *>(sg + j);
+                // Two register sets, A and B, each fetched while the other one is being consumed (the scalar
+                // cache's latency hides under 8 * K interactions) and each dead before its refill is issued, so
+                // no set is ever copied.  g0 is even (range starts are 64-aligned) and a block ends on an odd
+                // group index, so only the second group of a pair can close one.  The refill address is clamped to
+                // the last group instead of branching around the load.
+                const uint32_t j_last = j + (groups - 1) * 8;
+                v16f PA = *reinterpret_cast<const v16f *>(sp + 2 * (size_t)j);
+                v8f GA = *reinterpret_cast<const v8f *>(sg + j);
+                uint32_t g = 0;
+                while (g + 2 <= groups) {
+                    // pairs up to the end of the current 32-group block, as one branch-free inner loop
+                    const uint32_t to_close = (8u * CLOSE_EVERY - ((g0 + g) & (8u * CLOSE_EVERY - 1))) / 2;
+                    const uint32_t pairs = min(to_close, (groups - g) / 2);
+                    for (uint32_t i = 0; i < pairs; i++) {
+                        // Scalar loads return out of order, so the only wait there is is "all of them"
+                        // (lgkmcnt(0)).  The empty asm makes the next fetch's address depend on the set about to
+                        // be consumed: the wait lands BEFORE that fetch is issued, where nothing is in flight but
+                        // loads that had a whole group's math to land.  (Not volatile: a volatile asm counts as a
+                        // memory clobber and would turn the scalar loads into vector loads.)  The scheduling
+                        // barriers keep each fetch ahead of the math that hides it.
+                        asm("" : "+s"(j) : "s"(PA), "s"(GA));
+                        const v16f PB = *reinterpret_cast<const v16f *>(sp + 2 * (size_t)(j + 8));
+                        const v8f GB = *reinterpret_cast<const v8f *>(sg + j + 8);
+                        __builtin_amdgcn_sched_barrier(0);
+                        interact8<K, true>(R, PA, GA);
+                        __builtin_amdgcn_sched_barrier(0);
+                        j = min(j + 16, j_last);
+                        asm("" : "+s"(j) : "s"(PB), "s"(GB));
+                        PA = *reinterpret_cast<const v16f *>(sp + 2 * (size_t)j);
+                        GA = *reinterpret_cast<const v8f *>(sg + j);
+                        __builtin_amdgcn_sched_barrier(0);
+                        interact8<K, true>(R, PB, GB);
                     }
-                    interact8<K, true>(R, Pc, Gc);
-                    if (((g0 + g) & (8u * CLOSE_EVERY - 1)) == 8u * CLOSE_EVERY - 1) R.close_chunk();
+                    g += 2 * pairs;
+                    if (pairs == to_close) R.close_chunk();
                 }
+                if (g < groups) interact8<K, true>(R, PA, GA);  // odd count: the last refill fetched it
+                j = j_last + 8;
             }
             for (; j < j_end; j++) interact<K, true>(R, f2v{sp[2 * (size_t)j], sp[2 * (size_t)j + 1]}, sg[j]);
         }
