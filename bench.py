@@ -209,6 +209,8 @@ def main():
         shape, info, sim = nb.plan_launch(plan["mass_count"] + plan["zero_count"], plan["src_padded"]), "dry-run", None
     else:
         sim = nb.SimPipeline(n, mass_len, rank=rank, nranks=world, unique_id=uid if sharded else None)
+        if not sharded:
+            sim.configure(graph=1)   # the K-step chain runs as a hipGraph on its first use, built inside the timed call
         sim.set_data(part)           # H2D + SoA split: outside the timed region
 
         if args.warmup > 0:

@@ -119,7 +119,10 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
  *   "passes"    launches per step over consecutive source sub-ranges, chained through acc[]: 0 = auto (each
  *               pass's sources fit one XCD's L2, so they are fetched once per pass instead of once per round:
  *               23x less memory-side traffic at N = 2^20, same speed), else 1..64
- *   "graph"     1 = run step chains as hipGraphs (default), 0 = plain stream launches
+ *   "graph"     how PerformSimUpdate(n > 1) runs its chain: 1 = always as a hipGraph (built on first use, cached,
+ *               patched when dt changes), 0 = plain stream launches, 2 (default) = a chain length runs as plain
+ *               launches the first time it is asked for and as a hipGraph from the second time on (building a
+ *               chain costs more than one replay saves)
  *   "sharded_graph"  sharded pipelines: 1 = capture the {kernel, all-gather} x n chain into a hipGraph and replay
  *               it (non-overlapped step only); 0 = plain stream launches (default)
  *   "overlap"   sharded pipelines: 1 = split each step into own-shard / remote-shard kernels

@@ -444,6 +444,40 @@ const void *pick(int k, int w) {
 
 }  // namespace
 
+// Launches that do not even fill the chip once with K = 2 / W = 16 workgroups (fewer than 65 536 receivers on 256
+// CUs) are priced in microseconds by a model fitted to exhaustive (K, W, split) scans at N = 1 000 ... 50 000
+// (tools/sweep_shapes.py, profiles/r01_sweep15_shape_scan_small_n.txt).  There a wave is latency-bound, not
+// issue-bound: alone on its SIMD it needs LAT us per 64-source chunk and receiver set (a serial dependency chain),
+// and only beyond LAT / THR ~ 2.3 waves per SIMD does the chunk time grow with occupancy.  Cutting the sources into
+// more parts shortens every wave's chain, so small launches want splits the big-launch model would never pay for:
+// N = 4 000 runs 6.9 us per step with 4 parts instead of 10.1 us unsplit.
+static double small_launch_cost_us(uint32_t n_recv, uint32_t n_src, int k, int w, int sp, int cus) {
+    constexpr double LAT = 1.77, THR = 0.756, K1 = 1.023, MIX = 0.26, TAIL = 0.0217;
+    constexpr double FINISH = 1.30, FINISH_PER_PART = 0.0987, PARTS_BYTES_PER_US = 2.0e6;
+    const uint32_t chunks = (n_src + CHUNK - 1) / CHUNK;
+    const uint64_t groups = ((uint64_t)n_recv + WAVE * k - 1) / (WAVE * k) * (uint64_t)sp;
+    const uint64_t capacity = (uint64_t)cus * (32 / w);
+    const uint64_t full = groups / capacity, left = groups % capacity;
+    const uint32_t part_chunks = (chunks + sp - 1) / sp;
+    const uint32_t wave_chunks = (part_chunks + w - 1) / w;
+    const double units = (double)k * (wave_chunks ? wave_chunks : 1);
+    const double f = k == 1 ? K1 : 1.0;
+    const double unit_full = 8.0 * THR * f;  // a chunk with 8 waves on every SIMD
+    double t = (double)full * units * unit_full;
+    if (left) {
+        // the busiest CU holds ceil(left / CUs) workgroups of w waves on its 4 SIMDs
+        double occ = (w / 4.0) * (double)((left + cus - 1) / cus);
+        if (occ > 8.0) occ = 8.0;
+        const double lock = units * (LAT > occ * THR * f ? LAT : occ * THR * f);  // runs after the full rounds
+        const double fluid = units * unit_full * (double)left / (double)capacity;  // packs in behind them
+        t += full ? MIX * lock + (1.0 - MIX) * fluid : lock;
+    }
+    if (full) t += TAIL * units * unit_full;
+    if (sp > 1) t += FINISH + FINISH_PER_PART * sp + (double)n_recv * (24.0 + 8.0 * sp) / PARTS_BYTES_PER_US;
+    if (w == 4) t *= 1.05;  // 4-wave workgroups: the fit alone overrates them (N = 6 000: 12.0 us picked, 10.3 best)
+    return t;
+}
+
 LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int compute_units) {
     // Workgroups of one launch all take the same time, so a launch costs
     //     (rounds + tail) * (work per workgroup),   rounds = ceil(workgroups / resident capacity),
@@ -454,6 +488,7 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
     // occupancy, never faster (profiles/r01_sweep4_shapes_by_n.txt).
     if (compute_units <= 0) compute_units = 256;
     const uint32_t chunks = (n_src + CHUNK - 1) / CHUNK;
+    const bool small = ((uint64_t)n_recv + 2 * WAVE - 1) / (2 * WAVE) < (uint64_t)compute_units * 2;
     LaunchShape best = want;
     double best_cost = -1.0;
     for (int k = 2; k >= 1; k--) {
@@ -462,19 +497,24 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
             if (want.w != 0 && want.w != w) continue;
             for (int sp = 1; sp <= MAX_SPLIT; sp++) {
                 if (want.split != 0 && want.split != sp) continue;
-                const uint64_t groups = ((uint64_t)n_recv + WAVE * k - 1) / (WAVE * k) * (uint64_t)sp;
-                const uint64_t capacity = (uint64_t)compute_units * (32 / w);  // 8 waves per SIMD at <= 64 VGPRs
-                const uint64_t rounds = (groups + capacity - 1) / capacity;
-                const uint32_t part_chunks = (chunks + sp - 1) / sp;
-                const uint32_t wave_chunks = (part_chunks + w - 1) / w;
-                // + 1 chunk-equivalent per workgroup for prologue/epilogue; + TAIL rounds per launch for ramp-up and
-                // the ragged end (measured: 2-round launches run 4.5 % over, 16-round ones 0.1 % over:
-                // profiles/r01_shard_overhead_split.txt); a split adds the finish kernel and the parts traffic
-                constexpr double TAIL = 0.13;
-                double cost = ((double)rounds + TAIL) * ((double)k * (wave_chunks ? wave_chunks : 1) + 1.0);
-                if (sp > 1) cost += 3.0 + 0.02 * sp;
-                if (w < 16) cost *= 1.01;
-                if (k == 1) cost *= 1.25;  // measured: K = 1 is slower per interaction at large N
+                double cost;
+                if (small) {
+                    cost = small_launch_cost_us(n_recv, n_src, k, w, sp, compute_units);
+                } else {
+                    const uint64_t groups = ((uint64_t)n_recv + WAVE * k - 1) / (WAVE * k) * (uint64_t)sp;
+                    const uint64_t capacity = (uint64_t)compute_units * (32 / w);  // 8 waves per SIMD at <= 64 VGPRs
+                    const uint64_t rounds = (groups + capacity - 1) / capacity;
+                    const uint32_t part_chunks = (chunks + sp - 1) / sp;
+                    const uint32_t wave_chunks = (part_chunks + w - 1) / w;
+                    // + 1 chunk-equivalent per workgroup for prologue/epilogue; + TAIL rounds per launch for ramp-up
+                    // and the ragged end (measured: 2-round launches run 4.5 % over, 16-round ones 0.1 % over:
+                    // profiles/r01_shard_overhead_split.txt); a split adds the finish kernel and the parts traffic
+                    constexpr double TAIL = 0.13;
+                    cost = ((double)rounds + TAIL) * ((double)k * (wave_chunks ? wave_chunks : 1) + 1.0);
+                    if (sp > 1) cost += 3.0 + 0.02 * sp;
+                    if (w < 16) cost *= 1.01;
+                    if (k == 1) cost *= 1.25;  // measured: K = 1 is slower per interaction at large N
+                }
                 if (best_cost < 0.0 || cost < best_cost * 0.999) {
                     best_cost = cost;
                     best.k = k;

@@ -208,7 +208,8 @@ struct SimPipeline {
 
     // knobs
     int want_variant = nb::VARIANT_SMEM, want_k = 0, want_w = 0, want_split = 0;  // SMEM measures 2.5 % faster than LDS tiles
-    int use_graph = 1, overlap = 0, sharded_graph = 0;
+    int use_graph = 2, overlap = 0, sharded_graph = 0;  // use_graph: 0 never, 1 always, 2 from a chain length's second use
+    std::vector<uint32_t> seen_chains;                  // chain lengths already run once as plain launches
     int want_passes = 0;  // source passes per step (0 = auto: keep each pass's sources within one XCD's L2)
     nb::LaunchShape last_shape = {0, 0, 0, 0};
     uint32_t last_groups = 0;
@@ -442,13 +443,17 @@ void fill_node(hipKernelNodeParams &kp, void **args, const void *fn, dim3 grid, 
     kp.extra = nullptr;
 }
 
-StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchShape sh) {
-    const uint32_t passes = passes_for(s, whole_step(s, s->cur, dt));
-    StepGraph *g = nullptr;
+StepGraph *find_graph(SimPipeline *s, uint32_t n, uint32_t passes, nb::LaunchShape sh) {
     for (auto &c : s->graphs)
         if (c.n == n && c.passes == passes && c.shape.k == sh.k && c.shape.w == sh.w && c.shape.variant == sh.variant &&
             c.shape.split == sh.split)
-            g = &c;
+            return &c;
+    return nullptr;
+}
+
+StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchShape sh) {
+    const uint32_t passes = passes_for(s, whole_step(s, s->cur, dt));
+    StepGraph *g = find_graph(s, n, passes, sh);
     const uint32_t per_pass = sh.split > 1 ? 2 : 1;  // step kernel (+ finish kernel)
     const uint32_t per_step = passes * per_pass;
     const bool fresh = g == nullptr;
@@ -508,6 +513,23 @@ void enqueue_single(SimPipeline *s, uint32_t n, float dt) {
     while (left > 0) {
         // full chains have even length so that replaying them keeps the ping-pong phase
         const uint32_t chunk = left > GRAPH_CHAIN_MAX ? GRAPH_CHAIN_MAX : left;
+        if (s->use_graph == 2 && !find_graph(s, chunk, passes_for(s, whole_step(s, s->cur, dt)), sh)) {
+            // Building and instantiating a chain costs ~3 us per node, more than it saves in one run (a graph
+            // replay saves 1-2 us per step below N ~ 10 000 and nothing above: profiles/r01_graph_build_vs_replay.txt).
+            // A caller that steps the same n again and again -- a frame loop -- gets the graph from its second
+            // call; a one-off call (the reference's nbody-bench times exactly one) never pays for it.
+            bool seen = false;
+            for (uint32_t c : s->seen_chains) seen = seen || c == chunk;
+            if (!seen) {
+                s->seen_chains.push_back(chunk);
+                for (uint32_t i = 0; i < chunk; i++) {
+                    launch_step(s, sh, whole_step(s, s->cur, dt), s->stream);
+                    s->cur ^= 1;
+                }
+                left -= chunk;
+                continue;
+            }
+        }
         StepGraph *g = find_or_build_graph(s, chunk, dt, sh);
         ASSERT_HIP(hipGraphLaunch(g->exec, s->stream), "hipGraphLaunch (%u steps)", chunk);
         if (chunk & 1) s->cur ^= 1;
@@ -730,7 +752,7 @@ SimPipeline *CreateSimPipeline(WorldData data) {
     const char *sp = getenv("NB_HIP_SPLIT");
     if (sp) s->want_split = atoi(sp);
     const char *gr = getenv("NB_HIP_GRAPH");
-    if (gr) s->use_graph = atoi(gr) ? 1 : 0;
+    if (gr) s->use_graph = atoi(gr) < 0 || atoi(gr) > 2 ? 2 : atoi(gr);
     return s;
 }
 
@@ -963,8 +985,9 @@ int nb_hip_configure(SimPipeline *s, const char *key, int value) {
         old = s->want_split;
         s->want_split = value;
     } else if (!strcmp(key, "graph")) {
+        NB_ASSERT(value >= 0 && value <= 2, "graph must be 0 (never), 1 (always) or 2 (from the second use), got %d", value);
         old = s->use_graph;
-        s->use_graph = value ? 1 : 0;
+        s->use_graph = value;
     } else if (!strcmp(key, "passes")) {
         NB_ASSERT(value >= 0 && value <= 64, "passes must be 0 (auto) .. 64, got %d", value);
         old = s->want_passes;

@@ -127,14 +127,19 @@ def test_launch_plan_round_boundaries_and_splits():
         # large grids: K = 2, W = 16, whole rounds; a modest split keeps the launch's ragged end small
         assert (p["k"], p["w"]) == (2, 16) and 1 <= p["split"] <= 8
         assert p["workgroups"] == n // 128 * p["split"] and p["workgroups"] % 512 == 0
-    for n, m in ((100000, 49944), (20000, 9956), (200000, 99899)):
+    for n, m in ((100000, 49944), (200000, 99899)):
         p = nb.plan_launch(n, m)
         assert p["split"] > 1 and p["workgroups"] == -(-n // (64 * p["k"])) * p["split"]    # off a boundary: split
         rounds = -(-p["workgroups"] // (256 * 32 // p["w"]))
         assert p["workgroups"] / (rounds * 256 * 32 // p["w"]) > 0.9                          # last round nearly full
-    for n, m in ((250, 119), (1000, 485), (4096, 1989)):
+    for n, m in ((250, 119), (1000, 485), (2000, 967)):
         p = nb.plan_launch(n, m)
         assert p["k"] == 1 and p["split"] == 1                                              # launch-bound: simplest
+    assert nb.plan_launch(20000, 9956)["split"] > 1                                         # unsplit: 69 us, split: 46 us
+    for n, m in ((3000, 1467), (4096, 1989), (6000, 2957)):
+        p = nb.plan_launch(n, m)
+        # latency-bound: every wave's serial chain is cut short by splitting the sources (10.1 -> 6.9 us at N = 4000)
+        assert p["k"] == 1 and 3 <= p["split"] <= 8
     for n, m in ((1, 0), (1, 1), (64, 64), (0, 0), (4194304, 2100000), (123457, 7)):
         p = nb.plan_launch(n, m)
         assert p["k"] in (1, 2) and p["w"] in (4, 8, 16) and 1 <= p["split"] <= 16

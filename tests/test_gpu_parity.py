@@ -169,31 +169,37 @@ def test_graph_chain_equals_plain_launches(golden, n_steps):
     assert a.tobytes() == b.tobytes()
 
 
-def test_split_calls_and_odd_phases(golden):
+@pytest.mark.parametrize("graph", [1, 2])
+def test_split_calls_and_odd_phases(golden, graph):
+    # graph = 2 (the default): a chain length runs as plain launches once, as a cached hipGraph from then on
     part, m = ob.partition(golden("ic_333.bin"))
-    want = run(part, m, 12, 0.01, graph=0)
+    want = run(part, m, 18, 0.01, graph=0)
     sim = nb.SimPipeline(333, m)
+    sim.configure(graph=graph)
     sim.set_data(part)
-    for n in (3, 3, 1, 5):       # same chain length reused on the other ping-pong phase
+    for n in (3, 3, 1, 5, 3, 3):       # same chain length reused on the other ping-pong phase
         sim.update(n, 0.01)
     got = sim.get_data()
     sim.close()
     assert got.tobytes() == want.tobytes()
 
 
-def test_dt_change_patches_the_cached_chain(golden):
+@pytest.mark.parametrize("graph", [1, 2])
+def test_dt_change_patches_the_cached_chain(golden, graph):
     part, m = ob.partition(golden("ic_333.bin"))
     sim = nb.SimPipeline(333, m)
+    sim.configure(graph=graph)
     sim.set_data(part)
     sim.update(4, 0.01)
     sim.update(4, 0.005)         # same n, dt halved: kernel-node parameters are rewritten
     sim.update(4, 0.01)
+    sim.update(4, 0.0025)
     got = sim.get_data()
     sim.close()
     ref = nb.SimPipeline(333, m)
     ref.configure(graph=0)
     ref.set_data(part)
-    for dt in (0.01, 0.005, 0.01):
+    for dt in (0.01, 0.005, 0.01, 0.0025):
         ref.update(4, dt)
     want = ref.get_data()
     ref.close()
@@ -372,6 +378,7 @@ def test_baseline_sizes_spot_check(n, steps, dt):
     m = int((part[:, 6] > 0).sum())
     w.close()
     sim = nb.SimPipeline(n, m)
+    sim.configure(graph=1)                            # chains as hipGraphs from their first use (config 3)
     sim.set_data(part)
     sim.update(1, dt)
     one = sim.get_data()
