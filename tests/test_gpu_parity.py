@@ -245,6 +245,46 @@ def test_lds_and_smem_variants_agree_bitwise(golden, k, w):
     assert a.tobytes() == b.tobytes()
 
 
+def test_source_count_sweep_both_routes_agree_bitwise():
+    """The scalar-cache route walks its slice in pairs of 8-source groups inside 256-source blocks with a ragged tail;
+    the LDS route walks 64-source tiles.  Same arithmetic, same order: every source count around those boundaries
+    must give the same bits on both routes, for long slices (W = 1), short ones (W = 16) and split/passes."""
+    counts = sorted(set(list(range(1, 40)) + [63, 64, 65, 71, 72, 73, 127, 128, 129, 247, 248, 249, 255, 256, 257, 263, 264,
+                                              265, 511, 512, 513, 519, 520, 1023, 1024, 1025, 1031, 2047, 2048, 2049, 2111]))
+    for m_want in counts:
+        n = m_want + 37
+        part, m = synth(n, 1.0, seed=m_want)
+        part[m_want:, 6] = 0.0                       # exactly m_want sources, 37 massless receivers
+        part, m = ob.partition(part)
+        assert m == m_want
+        for knobs in (dict(k=1, w=1), dict(k=2, w=16), dict(k=2, w=4, split=3), dict(k=1, w=2, passes=2)):
+            a = run(part, m, 2, 0.01, variant=0, **knobs)
+            b = run(part, m, 2, 0.01, variant=1, **knobs)
+            assert a.tobytes() == b.tobytes(), f"routes differ at {m_want} sources, {knobs}"
+        if m_want in (1, 9, 64, 257, 1031):
+            check_one_step(run(part, m, 1, 0.01, variant=1, k=1, w=1), part, m, 0.01)
+
+
+@pytest.mark.parametrize("P,n,frac", [(2, 700, 0.9), (3, 1500, 0.6), (8, 5000, 0.8), (5, 333, 1.0)])
+def test_overlapped_shards_both_routes_agree_bitwise(P, n, frac):
+    # the overlapped step walks two source ranges (own slice, then the rest): the second range starts mid-slice
+    part, m = synth(n, frac, seed=n + P)
+    outs = []
+    for variant in (0, 1):
+        g = nb.LocalShardGroup(n, m, P, overlap=1, variant=variant, k=2, w=4)
+        g.set_data(part)
+        g.step(2, 0.01)
+        outs.append(g.get_data(P - 1))
+        g.close()
+    assert outs[0].tobytes() == outs[1].tobytes()
+    g = nb.LocalShardGroup(n, m, P, overlap=1)
+    g.set_data(part)
+    g.step(1, 0.01)
+    got = g.get_data(0)
+    g.close()
+    check_one_step(got, part, m, 0.01)
+
+
 def test_deterministic(golden):
     part, m = ob.partition(golden("ic_4096.bin"))
     assert run(part, m, 3, 0.01).tobytes() == run(part, m, 3, 0.01).tobytes()
