@@ -156,3 +156,30 @@ def test_gpu_call_without_gpu_aborts_loudly():
     r = subprocess.run(["python", "-c", code], cwd=ROOT, capture_output=True, text=True)
     assert r.returncode != 0 and "SURVIVED" not in r.stdout
     assert "no HIP device" in r.stderr or "hipError" in r.stderr
+
+
+# The reference's error convention (src/lib/util.h:17-29): no return codes; every failure prints
+# `file:line [func] message` to stderr and abort()s.  Each case runs in a child process.
+ERROR_CASES = [
+    ("mass_len > total_len", "s = nb.SimPipeline(10, 11)", "mass_len 11 > total_len 10"),
+    ("unknown knob", "s = nb.SimPipeline(10, 5); s.configure(nonsense=1)", 'unknown knob "nonsense"'),
+    ("bad knob value", "s = nb.SimPipeline(10, 5); s.configure(k=3)", "k must be 0, 1, 2 or 4, got 3"),
+    ("bad graph mode", "s = nb.SimPipeline(10, 5); s.configure(graph=7)", "graph must be 0"),
+    ("update before set", "s = nb.SimPipeline(10, 5); s.update(1, 0.1)", None),
+    ("get before set", "s = nb.SimPipeline(10, 5); s.get_data()", None),
+    ("sharded without id", "import ctypes as C; L = nb.hip_lib(); "
+     "L.CreateSimPipelineSharded(nb.WorldData(10, 5, 0.0), 0, 2, None)", "needs the RCCL unique id"),
+    ("bad rank", "L = nb.hip_lib(); L.nb_hip_shard_plan(10, 5, 3, 2, None)", "rank 3 of 2"),
+]
+
+
+@pytest.mark.parametrize("name,code,needle", ERROR_CASES, ids=[c[0] for c in ERROR_CASES])
+def test_failures_print_file_line_func_and_abort(name, code, needle):
+    r = subprocess.run(["python", "-c", "import nbody_amd as nb\n" + code + "\nprint('SURVIVED')"],
+                       cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode != 0 and "SURVIVED" not in r.stdout, (r.stdout, r.stderr)
+    # file:line [function] ...
+    import re
+    assert re.search(r"\.(hip|c|cpp|h):\d+ \[\w+\]", r.stderr), r.stderr
+    if needle:
+        assert needle in r.stderr, r.stderr
