@@ -15,7 +15,9 @@
  *   --galaxies G   galaxies per universe  (default 2)
  *   --seed S       srand seed             (default 11037)
  *   --own-rng      draw the universes from MakeGalaxiesSeeded(seed + row) instead of libc rand()
- * and two more columns: interactions/s = N * mass_len * steps / time.
+ * and more columns: interactions/s = N * mass_len * steps / time per backend, and for the GPU the share of the
+ * fp32 roofline that is (14 flop per interaction, 157.3 TFLOP/s).  Several GPUs are driven one process per GPU
+ * (bench.py under torch.distributed.run, include/nbody_hip.h part 2), not from this single-process harness.
  */
 #include <stdbool.h>
 #include <stdio.h>
@@ -101,7 +103,7 @@ int main(int argc, char **argv) {
     if (use_cpu) printf("\t    CPU");
     if (use_gpu) printf("\t    GPU");
     if (use_cpu) printf("\t  CPU int/s");
-    if (use_gpu) printf("\t  GPU int/s");
+    if (use_gpu) printf("\t  GPU int/s\t GPU %%peak");
     printf("\n");
 
     for (uint32_t s = 0; s < n_sizes; s++) {
@@ -124,7 +126,9 @@ int main(int argc, char **argv) {
         if (use_cpu) printf("\t%7ld", (long)(cpu_s * 1e6));
         if (use_gpu) printf("\t%7ld", (long)(gpu_s * 1e6));
         if (use_cpu) printf("\t%11.3e", pairs / cpu_s);
-        if (use_gpu) printf("\t%11.3e", pairs / gpu_s);
+        /* roofline column: 14 flop per interaction (reference op count, sim_cpu.c:169-188) against the
+         * MI355X fp32 vector peak of 157.3 TFLOP/s -- the same convention as bench.py */
+        if (use_gpu) printf("\t%11.3e\t%9.1f", pairs / gpu_s, pairs / gpu_s * 14.0 / 157.3e12 * 100.0);
         printf("\n");
         fflush(stdout);
         free(ps);
