@@ -101,6 +101,37 @@ void nb_hip_sync(SimPipeline *sim);
 double nb_hip_last_step_ms(SimPipeline *sim, uint32_t *launches);
 
 /*
+ * Finish-kernel launches inside the interval nb_hip_last_step_ms reports (one per step-kernel launch when the
+ * launch shape splits the sources, else 0): the small O(N) kernel that adds the parts and integrates.
+ */
+uint32_t nb_hip_last_finish_launches(const SimPipeline *sim);
+
+/*
+ * Sharded pipelines (plain-launch chains): where the time of the most recent PerformSimUpdate went.  *kernel_ms =
+ * sum over its steps of the force+integrate kernels' device time, *comm_ms = sum of the all-gathers' device time
+ * (each bracketed by its own HIP event pair on the stream it ran on; in overlap mode the gather runs beside the
+ * kernels, so the two do not add up to the wall time).  Returns the number of steps covered (the first 256 of a
+ * call); 0 for unsharded pipelines and for chains replayed as a captured hipGraph.
+ */
+uint32_t nb_hip_last_step_breakdown(SimPipeline *sim, double *kernel_ms, double *comm_ms);
+
+/*
+ * What the pipeline's RCCL communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice /
+ * ncclGetVersion), the device time of the probe all-gather run at creation, and the file librccl was loaded from.
+ * Returns 1 when the pipeline owns a communicator, else 0 (then nranks/rank are the creation arguments).
+ * Any out pointer may be NULL.  This is the evidence that N ranks really formed one communicator.
+ */
+int nb_hip_comm_info(const SimPipeline *sim, int *nranks, int *rank, int *device, int *rccl_version,
+                     double *first_gather_ms, char *lib_path, uint32_t len);
+
+/* Cached hipGraph chains of this pipeline (at most 8, least recently used evicted); *patches = times a cached
+ * chain's kernel-node parameters were rewritten because dt changed. */
+uint32_t nb_hip_graph_stats(const SimPipeline *sim, uint32_t *patches);
+
+/* hipRuntimeGetVersion() of the HIP runtime this process actually bound (0 when it cannot be asked). */
+int nb_hip_runtime_version(void);
+
+/*
  * Optional: tell the pipeline which long-lived host array Set/GetSimulationData will be called with (the World's
  * particle array).  It is page-locked (hipHostRegister) when the pipeline first touches the GPU and released in
  * DestroySimPipeline, so the hand-over runs at PCIe speed instead of through pageable memory.  The array must stay
@@ -112,15 +143,16 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
 /*
  * Tuning knobs.  key is one of:
  *   "variant"   0 = wave-private LDS tiles, 1 = scalar-cache (SMEM) source broadcast (default: measured 2.5 % faster)
- *   "k"         receivers per lane: 0 = auto, else 1, 2 or 4
- *   "w"         waves (source slices) per workgroup: 0 = auto, else 1, 2, 4, 8 or 16
+ *   "k"         receivers per lane: 0 = auto, else 1 or 2 (4 only in TUNING=1 builds)
+ *   "w"         waves (source slices) per workgroup: 0 = auto (4, 8 or 16), else 1, 4, 8 or 16 (2 only in TUNING=1
+ *               builds); w = 1 makes the summation order independent of the launch geometry
  *   "split"     workgroups per receiver tile, each over 1/split of the sources (a second small kernel adds
  *               the parts and integrates): 0 = auto (fills the chip / lands on a round boundary), else 1..16
  *   "passes"    launches per step over consecutive source sub-ranges, chained through acc[]: 0 = auto (each
  *               pass's sources fit one XCD's L2, so they are fetched once per pass instead of once per round:
  *               23x less memory-side traffic at N = 2^20, same speed), else 1..64
  *   "graph"     how PerformSimUpdate(n > 1) runs its chain: 1 = always as a hipGraph (built on first use, cached,
- *               patched when dt changes), 0 = plain stream launches, 2 (default) = a chain length runs as plain
+ *               per (length, ping-pong phase), patched when dt changes), 0 = plain stream launches, 2 (default) = a chain length runs as plain
  *               launches the first time it is asked for and as a hipGraph from the second time on (building a
  *               chain costs more than one replay saves)
  *   "sharded_graph"  sharded pipelines: 1 = capture the {kernel, all-gather} x n chain into a hipGraph and replay

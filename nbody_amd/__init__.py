@@ -47,6 +47,12 @@ HIP_API = {
     "nb_hip_step_async": (None, [C.c_void_p, C.c_uint32, C.c_float]),
     "nb_hip_sync": (None, [C.c_void_p]),
     "nb_hip_last_step_ms": (C.c_double, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "nb_hip_last_finish_launches": (C.c_uint32, [C.c_void_p]),
+    "nb_hip_last_step_breakdown": (C.c_uint32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "nb_hip_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_char_p, C.c_uint32]),
+    "nb_hip_graph_stats": (C.c_uint32, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "nb_hip_runtime_version": (C.c_int, []),
     "nb_hip_note_host_array": (None, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "nb_hip_configure": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "nb_hip_launch_shape": (None, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
@@ -204,6 +210,28 @@ class SimPipeline:
         launches = C.c_uint32(0)
         ms = hip_lib().nb_hip_last_step_ms(self._h, C.byref(launches))
         return float(ms), int(launches.value)
+
+    def finish_launches(self):
+        return int(hip_lib().nb_hip_last_finish_launches(self._h))
+
+    def step_breakdown(self):
+        """(steps covered, kernel ms, all-gather ms) of the last update of a sharded pipeline."""
+        k, c = C.c_double(0.0), C.c_double(0.0)
+        steps = hip_lib().nb_hip_last_step_breakdown(self._h, C.byref(k), C.byref(c))
+        return int(steps), float(k.value), float(c.value)
+
+    def comm_info(self):
+        """What the RCCL communicator itself reports (ncclCommCount etc.); owns_comm False when there is none."""
+        n, r, d, v, ms = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_double()
+        path = C.create_string_buffer(256)
+        own = hip_lib().nb_hip_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d), C.byref(v), C.byref(ms), path, 256)
+        return {"owns_comm": bool(own), "nranks": n.value, "rank": r.value, "device": d.value, "rccl_version": v.value,
+                "first_gather_ms": ms.value, "rccl_lib": path.value.decode()}
+
+    def graph_stats(self):
+        patches = C.c_uint32(0)
+        cached = hip_lib().nb_hip_graph_stats(self._h, C.byref(patches))
+        return {"cached": int(cached), "patches": int(patches.value)}
 
     def configure(self, **knobs):
         for k, v in knobs.items():

@@ -52,8 +52,8 @@ struct StepParams {
 };
 
 struct LaunchShape {
-    int k;        // receivers per lane: 1, 2, 4
-    int w;        // waves per workgroup = source slices: 1, 2, 4, 8, 16
+    int k;        // receivers per lane: 1, 2 (4 in tuning builds)
+    int w;        // waves per workgroup = source slices: 1, 4, 8, 16 (2 in tuning builds)
     int variant;  // VARIANT_*
     int split;    // workgroups per receiver tile (source parts): 1 .. MAX_SPLIT
 };
@@ -84,7 +84,8 @@ void launch_make_gm(hipStream_t st, const float *mass, float *gm, uint32_t count
 // merge: soa slots [slot0 .. slot0+count) -> aos[first .. first+count)
 void launch_merge(hipStream_t st, void *aos, uint32_t first, uint32_t count, const float2 *pos, const float2 *vel,
                   const float2 *acc, const float *radius, const float *mass, uint32_t slot0);
-// dst[i] = src[i] for float2 (device-side copy kernel usable inside graphs)
-void launch_copy_f2(hipStream_t st, float2 *dst, const float2 *src, uint32_t count);
+// sharded upload: both gathered source arrays + G*m from the AoS world; slots in [mass_len, n_src) become inert pads
+void launch_split_sources(hipStream_t st, const void *aos, uint32_t mass_len, uint32_t n_src, float2 *pos0, float2 *pos1,
+                          float *gm);
 
 }  // namespace nb

@@ -424,9 +424,22 @@ __global__ void make_gm_kernel(const float *mass, float *gm, uint32_t count) {
     gm[i] = m > 0.0f ? __fmul_rn(m, 10.0f) : 0.0f;  // NB_G * m, rounded as the reference's `gm = m * g`
 }
 
-__global__ void copy_f2_kernel(float2 *dst, const float2 *src, uint32_t count) {
+// Sharded upload: the gathered source arrays (both ping-pong buffers) and the static G*m straight from the AoS
+// world every rank holds.  Slots past mass_len are pads: far away, finite, massless (exact zero contribution).
+__global__ void split_sources_kernel(const ParticleRec *aos, uint32_t mass_len, uint32_t n_src, float2 *pos0, float2 *pos1,
+                                     float *gm) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) dst[i] = src[i];
+    if (i >= n_src) return;
+    float2 q = make_float2(1.0e15f, 1.0e15f);
+    float g = 0.0f;
+    if (i < mass_len) {
+        const ParticleRec r = aos[i];
+        q = make_float2(r.a.x, r.a.y);
+        g = r.b.z > 0.0f ? __fmul_rn(r.b.z, 10.0f) : 0.0f;  // NB_G * m, rounded as the reference's `gm = m * g`
+    }
+    pos0[i] = q;
+    pos1[i] = q;
+    gm[i] = g;
 }
 
 inline dim3 grid1d(uint32_t count) { return dim3((count + 255u) / 256u); }
@@ -435,9 +448,15 @@ template <int VARIANT>
 const void *pick(int k, int w) {
 #define NB_CASE(KK, WW) \
     if (k == KK && w == WW) return reinterpret_cast<const void *>(&step_kernel<KK, WW, VARIANT>);
-    NB_CASE(1, 1) NB_CASE(1, 2) NB_CASE(1, 4) NB_CASE(1, 8) NB_CASE(1, 16)
-    NB_CASE(2, 1) NB_CASE(2, 2) NB_CASE(2, 4) NB_CASE(2, 8) NB_CASE(2, 16)
+    // W = 4, 8, 16 are what choose_shape picks from; W = 1 is the shape whose summation order does not depend on
+    // how the sources are cut up (one wave walks them all), which the sharded-vs-single bit-equality tests rely on.
+    NB_CASE(1, 1) NB_CASE(1, 4) NB_CASE(1, 8) NB_CASE(1, 16)
+    NB_CASE(2, 1) NB_CASE(2, 4) NB_CASE(2, 8) NB_CASE(2, 16)
+#ifdef NB_TUNING_SHAPES
+    // never auto-selected (profiles/r01_sweep4_shapes_by_n.txt): built only for shape scans (make TUNING=1)
+    NB_CASE(1, 2) NB_CASE(2, 2)
     NB_CASE(4, 1) NB_CASE(4, 2) NB_CASE(4, 4) NB_CASE(4, 8) NB_CASE(4, 16)
+#endif
 #undef NB_CASE
     return nullptr;
 }
@@ -524,7 +543,7 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
             }
         }
     }
-    if (best_cost < 0.0) {  // explicit k = 4 or w in {1, 2}: honour the request as given
+    if (best_cost < 0.0) {  // explicit w = 1 (or a tuning-build shape): honour the request as given
         best.k = want.k ? want.k : 2;
         best.w = want.w ? want.w : 16;
         best.split = want.split ? want.split : 1;
@@ -569,9 +588,11 @@ void launch_merge(hipStream_t st, void *aos, uint32_t first, uint32_t count, con
                        vel, acc, radius, mass, slot0);
 }
 
-void launch_copy_f2(hipStream_t st, float2 *dst, const float2 *src, uint32_t count) {
-    if (count == 0) return;
-    hipLaunchKernelGGL(copy_f2_kernel, grid1d(count), dim3(256), 0, st, dst, src, count);
+void launch_split_sources(hipStream_t st, const void *aos, uint32_t mass_len, uint32_t n_src, float2 *pos0, float2 *pos1,
+                          float *gm) {
+    if (n_src == 0) return;
+    hipLaunchKernelGGL(split_sources_kernel, grid1d(n_src), dim3(256), 0, st, static_cast<const ParticleRec *>(aos), mass_len,
+                       n_src, pos0, pos1, gm);
 }
 
 }  // namespace nb

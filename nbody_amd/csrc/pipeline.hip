@@ -17,7 +17,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "kernels.h"
@@ -66,7 +71,12 @@ struct Rccl {
     int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*CommCount)(const ncclComm_t, int *) = nullptr;
+    int (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    int (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
+    int (*GetVersion)(int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    char path[256] = {0};  // file the symbols came from (dladdr), for the record
 };
 
 Rccl &rccl() {
@@ -85,8 +95,15 @@ Rccl &rccl() {
     NB_SYM(CommInitRank, "ncclCommInitRank");
     NB_SYM(CommDestroy, "ncclCommDestroy");
     NB_SYM(AllGather, "ncclAllGather");
+    NB_SYM(CommCount, "ncclCommCount");
+    NB_SYM(CommUserRank, "ncclCommUserRank");
+    NB_SYM(CommCuDevice, "ncclCommCuDevice");
+    NB_SYM(GetVersion, "ncclGetVersion");
     NB_SYM(GetErrorString, "ncclGetErrorString");
 #undef NB_SYM
+    Dl_info where;
+    if (dladdr(reinterpret_cast<void *>(r.AllGather), &where) && where.dli_fname)
+        snprintf(r.path, sizeof r.path, "%s", where.dli_fname);
     return r;
 }
 
@@ -99,6 +116,57 @@ Rccl &rccl() {
             NB_FAIL(__VA_ARGS__);                                                                             \
         }                                                                                                     \
     } while (0)
+
+// A collective that never completes (a rank that died, a fabric that does not come up) must not hang the job: the
+// calls that wait on other ranks -- ncclCommInitRank and the first all-gather -- run under a watchdog that prints
+// what was being waited for, the tail of RCCL's own log when NCCL_DEBUG_FILE names one, and _exit(3)s.  No retry and
+// no re-exec: the process has initialised the GPU.  NB_HIP_COMM_TIMEOUT_S (default 180) sets the bound; 0 disables it.
+class Watchdog {
+  public:
+    Watchdog(const char *what, int rank, int nranks) : what_(what), rank_(rank), nranks_(nranks) {
+        const char *t = getenv("NB_HIP_COMM_TIMEOUT_S");
+        seconds_ = t ? atoi(t) : 180;
+        if (seconds_ > 0) th_ = std::thread([this] { run(); });
+    }
+    ~Watchdog() {
+        if (!th_.joinable()) return;
+        {
+            std::lock_guard<std::mutex> l(m_);
+            done_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+
+  private:
+    void run() {
+        std::unique_lock<std::mutex> l(m_);
+        if (cv_.wait_for(l, std::chrono::seconds(seconds_), [this] { return done_; })) return;
+        fprintf(stderr, "%s [watchdog] rank %d of %d: %s did not complete within %d s; giving up (exit 3)\n", __FILE__,
+                rank_, nranks_, what_, seconds_);
+        const char *log = getenv("NCCL_DEBUG_FILE");
+        if (log && !strchr(log, '%')) {
+            if (FILE *f = fopen(log, "r")) {
+                fseek(f, 0, SEEK_END);
+                long sz = ftell(f);
+                fseek(f, sz > 4096 ? sz - 4096 : 0, SEEK_SET);
+                char buf[4097];
+                size_t got = fread(buf, 1, 4096, f);
+                buf[got] = 0;
+                fprintf(stderr, "---- tail of %s ----\n%s\n", log, buf);
+                fclose(f);
+            }
+        }
+        fflush(stderr);
+        _exit(3);
+    }
+    const char *what_;
+    int rank_, nranks_, seconds_ = 0;
+    bool done_ = false;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::thread th_;
+};
 
 // ---- process-wide device context (the reference keeps one global vulkan_ctx, vulkan_ctx.c:11) -------------
 
@@ -133,6 +201,14 @@ void ensure_device() {
     g_dev.ready = true;
 }
 
+// HIP's current device is per THREAD: every entry point that allocates, launches or copies re-selects the
+// process' device, so a call from another thread than the first one lands on the same GPU (ordinal > 0 matters:
+// sharded ranks use LOCAL_RANK).
+void use_device() {
+    ensure_device();
+    ASSERT_HIP(hipSetDevice(g_dev.ordinal), "hipSetDevice(%d)", g_dev.ordinal);
+}
+
 template <typename T>
 T *dev_alloc(size_t count) {
     T *p = nullptr;
@@ -159,6 +235,27 @@ struct StepGraph {
     int phase = -1;                     // which pos buffer the chain reads first
     float dt = 0.0f;
     nb::LaunchShape shape = {0, 0, 0, 0};
+    uint64_t last_use = 0;              // for eviction: the cache holds at most GRAPH_CACHE_MAX chains
+};
+
+// Event pairs around the kernels and the gathers of a sharded chain (the plain-launch path), so that a multi-GPU
+// run can say how much of a step was the all-gather.  Grown on demand, reused by every call.
+struct EventPool {
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    hipEvent_t next() {
+        if (used == ev.size()) {
+            hipEvent_t e;
+            ASSERT_HIP(hipEventCreate(&e), "event");
+            ev.push_back(e);
+        }
+        return ev[used++];
+    }
+    void destroy() {
+        for (hipEvent_t e : ev) ASSERT_HIP(hipEventDestroy(e), "event");
+        ev.clear();
+        used = 0;
+    }
 };
 
 }  // namespace
@@ -204,13 +301,21 @@ struct SimPipeline {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     hipEvent_t ev_local = nullptr, ev_gather = nullptr;
     bool timed = false;
-    uint32_t timed_launches = 0;
+    uint32_t timed_launches = 0;         // step-kernel launches between ev_begin and ev_end
+    uint32_t timed_finish_launches = 0;  // finish-kernel launches in the same interval (split shapes only)
+    // sharded plain-launch chains: [begin, end) event pairs of each step's kernels and of each gather
+    EventPool pool;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> kernel_iv, comm_iv;
+    uint32_t detail_steps = 0;  // steps the intervals above cover (capped)
+    uint64_t use_clock = 0;     // ticks once per graph lookup (LRU)
 
     // knobs
     int want_variant = nb::VARIANT_SMEM, want_k = 0, want_w = 0, want_split = 0;  // SMEM measures 2.5 % faster than LDS tiles
     int use_graph = 2, overlap = 0, sharded_graph = 0;  // use_graph: 0 never, 1 always, 2 from a chain length's second use
     std::vector<uint32_t> seen_chains;                  // chain lengths already run once as plain launches
     int want_passes = 0;  // source passes per step (0 = auto: keep each pass's sources within one XCD's L2)
+    double first_gather_ms = 0.0;  // sharded: device time of the probe all-gather at creation (includes lazy setup)
+    uint32_t graph_patches = 0;  // times a cached chain's nodes were rewritten (dt changed); tooling reads it
     nb::LaunchShape last_shape = {0, 0, 0, 0};
     uint32_t last_groups = 0;
 
@@ -220,6 +325,7 @@ struct SimPipeline {
 namespace {
 
 constexpr uint32_t GRAPH_CHAIN_MAX = 64;  // longer requests replay an even-length chain
+constexpr size_t GRAPH_CACHE_MAX = 8;     // cached chains per pipeline; the least recently used one is evicted
 
 void destroy_graph(StepGraph &g) {
     if (g.exec) ASSERT_HIP(hipGraphExecDestroy(g.exec), "hipGraphExecDestroy");
@@ -247,9 +353,27 @@ void pin_host(SimPipeline *s) {
         (void)hipGetLastError();  // not fatal: copies stay correct, only slower
 }
 
+// Make room for one more cached chain: the least recently used one goes (a frame loop with a varying chain length
+// or dt must not grow device-side graph execs without bound).
+void evict_for_one_more(SimPipeline *s) {
+    while (s->graphs.size() >= GRAPH_CACHE_MAX) {
+        size_t victim = 0;
+        for (size_t i = 1; i < s->graphs.size(); i++)
+            if (s->graphs[i].last_use < s->graphs[victim].last_use) victim = i;
+        ASSERT_HIP(hipStreamSynchronize(s->stream), "sync before evicting a cached chain");
+        destroy_graph(s->graphs[victim]);
+        s->graphs.erase(s->graphs.begin() + (long)victim);
+    }
+}
+
 void release_device(SimPipeline *s) {
     if (!s->on_device) return;
+    use_device();
     ASSERT_HIP(hipStreamSynchronize(s->stream), "sync before release");
+    if (s->comm_stream) ASSERT_HIP(hipStreamSynchronize(s->comm_stream), "sync before release");
+    s->pool.destroy();
+    s->kernel_iv.clear();
+    s->comm_iv.clear();
     unpin_host(s);
     for (auto &g : s->graphs) destroy_graph(g);
     s->graphs.clear();
@@ -279,8 +403,8 @@ void release_device(SimPipeline *s) {
 
 // First touch of the GPU for this pipeline: stream, events, HBM buffers.
 void materialize(SimPipeline *s) {
+    use_device();
     if (s->on_device) return;
-    ensure_device();
     if (s->group)
         s->stream = s->group->stream;
     else
@@ -443,21 +567,27 @@ void fill_node(hipKernelNodeParams &kp, void **args, const void *fn, dim3 grid, 
     kp.extra = nullptr;
 }
 
-StepGraph *find_graph(SimPipeline *s, uint32_t n, uint32_t passes, nb::LaunchShape sh) {
+// A cached chain is keyed on (length, passes, shape, PHASE): an odd chain length flips the ping-pong phase, so a
+// frame loop that asks for the same odd n alternates between two phases -- with the phase in the key it gets two
+// instantiated graphs and replays them untouched, instead of re-patching every node of one graph on every call.
+// dt is not part of the key: a changed dt patches the node parameters in place (the analogue of the reference
+// re-uploading its uniform, sim_gpu.c:268-284).
+StepGraph *find_graph(SimPipeline *s, uint32_t n, uint32_t passes, nb::LaunchShape sh, int phase) {
     for (auto &c : s->graphs)
-        if (c.n == n && c.passes == passes && c.shape.k == sh.k && c.shape.w == sh.w && c.shape.variant == sh.variant &&
-            c.shape.split == sh.split)
+        if (c.n == n && c.passes == passes && c.phase == phase && c.shape.k == sh.k && c.shape.w == sh.w &&
+            c.shape.variant == sh.variant && c.shape.split == sh.split)
             return &c;
     return nullptr;
 }
 
 StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchShape sh) {
     const uint32_t passes = passes_for(s, whole_step(s, s->cur, dt));
-    StepGraph *g = find_graph(s, n, passes, sh);
+    StepGraph *g = find_graph(s, n, passes, sh, s->cur);
     const uint32_t per_pass = sh.split > 1 ? 2 : 1;  // step kernel (+ finish kernel)
     const uint32_t per_step = passes * per_pass;
     const bool fresh = g == nullptr;
     if (fresh) {
+        evict_for_one_more(s);
         s->graphs.emplace_back();
         g = &s->graphs.back();
         g->n = n;
@@ -466,11 +596,12 @@ StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchS
         ASSERT_HIP(hipGraphCreate(&g->graph, 0), "hipGraphCreate");
         g->nodes.resize((size_t)n * per_step);
         g->params.resize((size_t)n * passes);
-    } else if (g->phase == s->cur && g->dt == dt) {
-        return g;
     }
+    g->last_use = ++s->use_clock;
+    if (!fresh && g->dt == dt) return g;
+    s->graph_patches += fresh ? 0 : 1;
     // (re)write every node: at creation, or -- the analogue of the reference re-uploading its uniform when dt
-    // changes (sim_gpu.c:268-284) -- patch the instantiated graph when dt or the ping-pong phase moved
+    // changes (sim_gpu.c:268-284) -- patch the instantiated graph when dt moved
     hipGraphNode_t prev = nullptr;
     for (uint32_t i = 0; i < n; i++) {
         const std::vector<nb::StepParams> launches = step_passes(s, whole_step(s, (s->cur + i) & 1, dt), sh);
@@ -513,7 +644,7 @@ void enqueue_single(SimPipeline *s, uint32_t n, float dt) {
     while (left > 0) {
         // full chains have even length so that replaying them keeps the ping-pong phase
         const uint32_t chunk = left > GRAPH_CHAIN_MAX ? GRAPH_CHAIN_MAX : left;
-        if (s->use_graph == 2 && !find_graph(s, chunk, passes_for(s, whole_step(s, s->cur, dt)), sh)) {
+        if (s->use_graph == 2 && !find_graph(s, chunk, passes_for(s, whole_step(s, s->cur, dt)), sh, s->cur)) {
             // Building and instantiating a chain costs ~3 us per node, more than it saves in one run (a graph
             // replay saves 1-2 us per step below N ~ 10 000 and nothing above: profiles/r01_graph_build_vs_replay.txt).
             // A caller that steps the same n again and again -- a frame loop -- gets the graph from its second
@@ -521,6 +652,7 @@ void enqueue_single(SimPipeline *s, uint32_t n, float dt) {
             bool seen = false;
             for (uint32_t c : s->seen_chains) seen = seen || c == chunk;
             if (!seen) {
+                if (s->seen_chains.size() >= 64) s->seen_chains.clear();
                 s->seen_chains.push_back(chunk);
                 for (uint32_t i = 0; i < chunk; i++) {
                     launch_step(s, sh, whole_step(s, s->cur, dt), s->stream);
@@ -559,15 +691,31 @@ void allgather_sources(SimPipeline *s, int buf, hipStream_t st) {
                 "ncclAllGather of %zu floats per rank", per_rank);
 }
 
+constexpr uint32_t DETAIL_STEPS_MAX = 256;  // steps per call whose kernels / gathers get their own event pairs
+
 // One sharded step of one rank.  `cs` carries the gather (the comm stream with RCCL; the group stream locally).
-void sharded_step(SimPipeline *s, nb::LaunchShape sh, float dt, hipStream_t cs) {
+// `detail`: bracket the step's kernels and its gather with event pairs (plain launches only, not under capture).
+void sharded_step(SimPipeline *s, nb::LaunchShape sh, float dt, hipStream_t cs, bool detail = false) {
     const uint32_t Mc = s->plan.mass_chunk;
     const uint32_t own_lo = (uint32_t)s->rank * Mc, own_hi = own_lo + Mc;
     const int in = s->cur;
+    auto mark = [&](hipStream_t st) -> hipEvent_t {
+        if (!detail) return nullptr;
+        hipEvent_t e = s->pool.next();
+        ASSERT_HIP(hipEventRecord(e, st), "record interval event");
+        return e;
+    };
     if (!s->overlap) {
         // one kernel over all gathered sources, then gather the positions it produced
+        const hipEvent_t k0 = mark(s->stream);
         launch_step(s, sh, whole_step(s, in, dt), s->stream);
+        const hipEvent_t k1 = mark(s->stream);  // end of the kernels == begin of the gather (same stream)
         allgather_sources(s, in ^ 1, s->stream);
+        const hipEvent_t g1 = mark(s->stream);
+        if (detail) {
+            s->kernel_iv.emplace_back(k0, k1);
+            s->comm_iv.emplace_back(k1, g1);
+        }
     } else {
         // own-shard sources are already here: start on them while the other P-1 slices of
         // src_pos[in] are still arriving on the comm stream, then finish with the remote ones
@@ -576,8 +724,11 @@ void sharded_step(SimPipeline *s, nb::LaunchShape sh, float dt, hipStream_t cs) 
         a.src_end[0] = own_hi;
         a.flags = nb::STEP_NO_FINALIZE;
         a.n_mirror = 0;
+        const hipEvent_t a0 = mark(s->stream);
         launch_step(s, sh, a, s->stream);
+        const hipEvent_t a1 = mark(s->stream);
         ASSERT_HIP(hipStreamWaitEvent(s->stream, s->ev_gather, 0), "wait gather");
+        const hipEvent_t b0 = mark(s->stream);  // stamped once the previous step's gather has landed
         nb::StepParams b = whole_step(s, in, dt);
         b.src_begin[0] = 0;
         b.src_end[0] = own_lo;
@@ -585,10 +736,18 @@ void sharded_step(SimPipeline *s, nb::LaunchShape sh, float dt, hipStream_t cs) 
         b.src_end[1] = s->n_src;
         b.flags = nb::STEP_ACC_IN;
         launch_step(s, sh, b, s->stream);
+        const hipEvent_t b1 = mark(s->stream);
         ASSERT_HIP(hipEventRecord(s->ev_local, s->stream), "record local");
         ASSERT_HIP(hipStreamWaitEvent(cs, s->ev_local, 0), "comm waits for the new slice");
+        const hipEvent_t g0 = mark(cs);
         allgather_sources(s, in ^ 1, cs);
+        const hipEvent_t g1 = mark(cs);
         ASSERT_HIP(hipEventRecord(s->ev_gather, cs), "record gather");
+        if (detail) {
+            s->kernel_iv.emplace_back(a0, a1);
+            s->kernel_iv.emplace_back(b0, b1);
+            s->comm_iv.emplace_back(g0, g1);
+        }
     }
     s->cur ^= 1;
 }
@@ -600,10 +759,14 @@ void sharded_step(SimPipeline *s, nb::LaunchShape sh, float dt, hipStream_t cs) 
 StepGraph *capture_sharded_chain(SimPipeline *s, uint32_t n, float dt, nb::LaunchShape sh) {
     for (auto &c : s->graphs)
         if (c.n == n && c.dt == dt && c.phase == s->cur && c.shape.k == sh.k && c.shape.w == sh.w &&
-            c.shape.variant == sh.variant && c.shape.split == sh.split)
+            c.shape.variant == sh.variant && c.shape.split == sh.split) {
+            c.last_use = ++s->use_clock;
             return &c;
+        }
+    evict_for_one_more(s);  // captured RCCL nodes pin communicator resources: the cache stays small
     s->graphs.emplace_back();
     StepGraph *g = &s->graphs.back();
+    g->last_use = ++s->use_clock;
     g->n = n;
     g->dt = dt;
     g->phase = s->cur;
@@ -631,13 +794,19 @@ void enqueue_sharded(SimPipeline *s, uint32_t n, float dt) {
         }
         return;
     }
-    for (uint32_t i = 0; i < n; i++) sharded_step(s, sh, dt, s->comm_stream);
+    for (uint32_t i = 0; i < n; i++) sharded_step(s, sh, dt, s->comm_stream, i < DETAIL_STEPS_MAX);
+    s->detail_steps = n < DETAIL_STEPS_MAX ? n : DETAIL_STEPS_MAX;
     if (s->overlap) ASSERT_HIP(hipStreamWaitEvent(s->stream, s->ev_gather, 0), "join comm stream");
 }
 
 void enqueue_steps(SimPipeline *s, uint32_t n, float dt) {
     NB_ASSERT(s->on_device, "PerformSimUpdate before SetSimulationData");
     if (s->slots == 0 || n == 0) return;
+    use_device();
+    s->pool.used = 0;
+    s->kernel_iv.clear();
+    s->comm_iv.clear();
+    s->detail_steps = 0;
     ASSERT_HIP(hipEventRecord(s->ev_begin, s->stream), "record begin");
     if (!s->sharded)
         enqueue_single(s, n, dt);
@@ -646,6 +815,7 @@ void enqueue_steps(SimPipeline *s, uint32_t n, float dt) {
     ASSERT_HIP(hipEventRecord(s->ev_end, s->stream), "record end");
     s->timed = true;
     s->timed_launches = (s->sharded && s->overlap) ? 2 * n : n * passes_for(s, whole_step(s, s->cur, dt));
+    s->timed_finish_launches = s->last_shape.split > 1 ? s->timed_launches : 0;
     s->data.dt = dt;
 }
 
@@ -779,10 +949,51 @@ SimPipeline *CreateSimPipelineSharded(WorldData data, int rank, int nranks, cons
     if (ov) s->overlap = atoi(ov) ? 1 : 0;
     const char *sg = getenv("NB_HIP_SHARDED_GRAPH");
     if (sg) s->sharded_graph = atoi(sg) ? 1 : 0;
-    ensure_device();  // the communicator binds to the current device
+    use_device();  // the communicator binds to the current device
     ncclUniqueId id;
     memcpy(&id, unique_id128, NB_HIP_UNIQUE_ID_BYTES);
-    ASSERT_NCCL(rccl().CommInitRank(&s->comm, nranks, id, rank), "ncclCommInitRank(rank %d of %d)", rank, nranks);
+    {
+        Watchdog dog("ncclCommInitRank", rank, nranks);
+        ASSERT_NCCL(rccl().CommInitRank(&s->comm, nranks, id, rank), "ncclCommInitRank(rank %d of %d)", rank, nranks);
+    }
+    // The communicator's own view must agree with what the caller said: this is what tells N real ranks from N
+    // independent replicas.
+    int seen_n = -1, seen_r = -1;
+    ASSERT_NCCL(rccl().CommCount(s->comm, &seen_n), "ncclCommCount");
+    ASSERT_NCCL(rccl().CommUserRank(s->comm, &seen_r), "ncclCommUserRank");
+    NB_ASSERT(seen_n == nranks && seen_r == rank, "communicator reports rank %d of %d, expected %d of %d", seen_r, seen_n,
+              rank, nranks);
+    // First collective, bounded: a 256-byte-per-rank all-gather of (rank + 1) tags, checked on arrival.  Pays RCCL's
+    // lazy channel setup here instead of inside the first timed step.
+    {
+        Watchdog dog("the first ncclAllGather", rank, nranks);
+        const size_t per = 64;
+        float *probe = dev_alloc<float>(per * (size_t)nranks);
+        std::vector<float> host(per * (size_t)nranks, 0.0f);
+        for (size_t i = 0; i < per; i++) host[(size_t)rank * per + i] = (float)(rank + 1);
+        hipStream_t st;
+        ASSERT_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "probe stream");
+        ASSERT_HIP(hipMemcpyAsync(probe, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, st), "probe H2D");
+        hipEvent_t e0, e1;
+        ASSERT_HIP(hipEventCreate(&e0), "event");
+        ASSERT_HIP(hipEventCreate(&e1), "event");
+        ASSERT_HIP(hipEventRecord(e0, st), "record");
+        ASSERT_NCCL(rccl().AllGather(probe + (size_t)rank * per, probe, per, NCCL_FLOAT32, s->comm, st), "first ncclAllGather");
+        ASSERT_HIP(hipEventRecord(e1, st), "record");
+        ASSERT_HIP(hipMemcpyAsync(host.data(), probe, host.size() * sizeof(float), hipMemcpyDeviceToHost, st), "probe D2H");
+        ASSERT_HIP(hipStreamSynchronize(st), "probe sync");
+        for (int q = 0; q < nranks; q++)
+            for (size_t i = 0; i < per; i++)
+                NB_ASSERT(host[(size_t)q * per + i] == (float)(q + 1), "first all-gather: slot of rank %d holds %g", q,
+                          (double)host[(size_t)q * per + i]);
+        float ms = 0.0f;
+        ASSERT_HIP(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+        s->first_gather_ms = (double)ms;
+        ASSERT_HIP(hipEventDestroy(e0), "event");
+        ASSERT_HIP(hipEventDestroy(e1), "event");
+        ASSERT_HIP(hipStreamDestroy(st), "probe stream");
+        dev_free(probe);
+    }
     return s;
 }
 
@@ -799,7 +1010,7 @@ void nb_hip_plan_launch(uint32_t n_recv, uint32_t n_src, int compute_units, int 
 
 int nb_hip_local_group_create(WorldData data, int nranks, SimPipeline **out) {
     NB_ASSERT(nranks >= 1 && out != nullptr, "bad local group request");
-    ensure_device();
+    use_device();
     LocalGroup *g = new LocalGroup();
     ASSERT_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking), "group stream");
     for (int r = 0; r < nranks; r++) {
@@ -820,6 +1031,7 @@ void nb_hip_local_group_step(SimPipeline **sims, int nranks, uint32_t n, float d
     LocalGroup *g = sims[0]->group;
     NB_ASSERT((int)g->members.size() == nranks, "group has %zu members, %d passed", g->members.size(), nranks);
     for (int r = 0; r < nranks; r++) NB_ASSERT(sims[r]->on_device, "member %d has no data", r);
+    use_device();
     for (uint32_t i = 0; i < n; i++)
         for (int r = 0; r < nranks; r++) {
             SimPipeline *s = sims[r];
@@ -867,19 +1079,7 @@ void SetSimulationData(SimPipeline *s, const Particle *ps) {
                          pl.mass_chunk);
         // sources: every rank holds the whole world in `aos`, so the first gathered array and the static
         // G*m need no communication: rank q's slice is aos[q*Mc ..) padded
-        float2 *scratch_vel = dev_alloc<float2>(s->n_src);
-        float2 *scratch_acc = dev_alloc<float2>(s->n_src);
-        float *scratch_rad = dev_alloc<float>(s->n_src);
-        float *scratch_mass = dev_alloc<float>(s->n_src);
-        nb::launch_fill_pad(st, s->src_pos[0], scratch_vel, scratch_acc, scratch_rad, scratch_mass, 0, s->n_src);
-        nb::launch_split(st, s->aos, 0, M, s->src_pos[0], scratch_vel, scratch_acc, scratch_rad, scratch_mass, 0);
-        nb::launch_make_gm(st, scratch_mass, s->src_gm, s->n_src);
-        nb::launch_copy_f2(st, s->src_pos[1], s->src_pos[0], s->n_src);
-        ASSERT_HIP(hipStreamSynchronize(st), "sync after source setup");
-        dev_free(scratch_vel);
-        dev_free(scratch_acc);
-        dev_free(scratch_rad);
-        dev_free(scratch_mass);
+        nb::launch_split_sources(st, s->aos, M, s->n_src, s->src_pos[0], s->src_pos[1], s->src_gm);
         if (s->overlap) ASSERT_HIP(hipEventRecord(s->ev_gather, s->group ? s->stream : s->comm_stream), "prime gather event");
     }
     ASSERT_HIP(hipStreamSynchronize(st), "sync after SetSimulationData");
@@ -891,6 +1091,7 @@ void GetSimulationData(const SimPipeline *cs, Particle *ps) {
     NB_ASSERT(s->on_device, "GetSimulationData before SetSimulationData");
     const uint32_t N = s->data.total_len;
     if (N == 0) return;
+    use_device();
     hipStream_t st = s->stream;
     if (!s->sharded) {
         nb::launch_merge(st, s->aos, 0, N, s->pos[s->cur], s->vel, s->acc, s->radius, s->mass, 0);
@@ -935,6 +1136,7 @@ void nb_hip_step_async(SimPipeline *s, uint32_t n, float dt) {
 void nb_hip_sync(SimPipeline *s) {
     NB_ASSERT(s != nullptr, "NULL pipeline");
     if (!s->on_device) return;
+    use_device();
     ASSERT_HIP(hipStreamSynchronize(s->stream), "stream sync");
     if (s->comm_stream) ASSERT_HIP(hipStreamSynchronize(s->comm_stream), "comm stream sync");
 }
@@ -955,8 +1157,67 @@ double nb_hip_last_step_ms(SimPipeline *s, uint32_t *launches) {
     return (double)ms;
 }
 
+uint32_t nb_hip_last_finish_launches(const SimPipeline *s) {
+    NB_ASSERT(s != nullptr, "NULL pipeline");
+    return s->timed ? s->timed_finish_launches : 0;
+}
+
+uint32_t nb_hip_last_step_breakdown(SimPipeline *s, double *kernel_ms, double *comm_ms) {
+    NB_ASSERT(s != nullptr, "NULL pipeline");
+    if (kernel_ms) *kernel_ms = 0.0;
+    if (comm_ms) *comm_ms = 0.0;
+    if (!s->on_device || !s->timed || s->detail_steps == 0) return 0;
+    use_device();
+    ASSERT_HIP(hipStreamSynchronize(s->stream), "stream sync");
+    if (s->comm_stream) ASSERT_HIP(hipStreamSynchronize(s->comm_stream), "comm stream sync");
+    auto total = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>> &iv) {
+        double sum = 0.0;
+        for (const auto &p : iv) {
+            float ms = 0.0f;
+            ASSERT_HIP(hipEventElapsedTime(&ms, p.first, p.second), "hipEventElapsedTime");
+            sum += (double)ms;
+        }
+        return sum;
+    };
+    if (kernel_ms) *kernel_ms = total(s->kernel_iv);
+    if (comm_ms) *comm_ms = total(s->comm_iv);
+    return s->detail_steps;
+}
+
+int nb_hip_comm_info(const SimPipeline *s, int *nranks, int *rank, int *device, int *rccl_version, double *first_gather_ms,
+                     char *lib_path, uint32_t len) {
+    NB_ASSERT(s != nullptr, "NULL pipeline");
+    if (nranks) *nranks = s->nranks;
+    if (rank) *rank = s->rank;
+    if (device) *device = g_dev.ordinal;
+    if (rccl_version) *rccl_version = 0;
+    if (first_gather_ms) *first_gather_ms = s->first_gather_ms;
+    if (lib_path && len) lib_path[0] = 0;
+    if (s->comm == nullptr) return 0;  // unsharded, or a local-group member: no communicator
+    // everything below is what the COMMUNICATOR says, not what the caller passed at creation
+    if (nranks) ASSERT_NCCL(rccl().CommCount(s->comm, nranks), "ncclCommCount");
+    if (rank) ASSERT_NCCL(rccl().CommUserRank(s->comm, rank), "ncclCommUserRank");
+    if (device) ASSERT_NCCL(rccl().CommCuDevice(s->comm, device), "ncclCommCuDevice");
+    if (rccl_version) ASSERT_NCCL(rccl().GetVersion(rccl_version), "ncclGetVersion");
+    if (lib_path && len) snprintf(lib_path, len, "%s", rccl().path);
+    return 1;
+}
+
+uint32_t nb_hip_graph_stats(const SimPipeline *s, uint32_t *patches) {
+    NB_ASSERT(s != nullptr, "NULL pipeline");
+    if (patches) *patches = s->graph_patches;
+    return (uint32_t)s->graphs.size();
+}
+
+int nb_hip_runtime_version(void) {
+    int v = 0;
+    if (hipRuntimeGetVersion(&v) != hipSuccess) return 0;
+    return v;
+}
+
 void nb_hip_note_host_array(SimPipeline *s, void *array, uint64_t bytes) {
     NB_ASSERT(s != nullptr, "NULL pipeline");
+    if (s->on_device) use_device();
     if (s->on_device) ASSERT_HIP(hipStreamSynchronize(s->stream), "sync before re-registering the host array");
     unpin_host(s);
     s->host_array = array;

@@ -1,0 +1,109 @@
+"""Static checks on the gfx950 ISA of the step kernels (no GPU needed: hipcc cross-compiles).
+
+The hot loop is hand-written asm (nbody_amd/csrc/kernels.hip, NB_INTERACTION_ASM) and leans on three invariants that
+only the GPU parity tests would otherwise notice:
+  1. gfx950 needs one wait state between a transcendental (v_rsq_f32) and the VALU instruction that reads its
+     result, and hipcc cannot pad inside an asm statement: the `s_setprio 0` that follows the rsq IS that wait state
+     (round 1 shipped-then-fixed a variant without it that read stale values);
+  2. every step kernel must stay within 64 VGPRs, or a 1024-thread workgroup no longer fits twice on a CU
+     (__launch_bounds__(1024, 8));
+  3. no scratch: a spill inside the inner loop would sit on the critical path.
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def isa(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = tmp_path_factory.mktemp("isa") / "kernels.s"
+    src = os.path.join(ROOT, "nbody_amd", "csrc", "kernels.hip")
+    # the flags of nbody_amd/csrc/Makefile (HIPFLAGS), device side only, assembly out
+    cmd = [HIPCC, "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-Wno-unused-command-line-argument",
+           f"-I{ROOT}/include", f"-I{ROOT}/nbody_amd/csrc", "--cuda-device-only", "-S", "-o", str(out), src]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    return out.read_text()
+
+
+def functions(text):
+    """name -> list of instruction lines (labels, directives and comments dropped)."""
+    out, name = {}, None
+    for line in text.splitlines():
+        m = re.match(r"^(_ZN2nb\S+):", line)
+        if m:
+            name = m.group(1)
+            out[name] = []
+            continue
+        if line.startswith(".Lfunc_end"):
+            name = None
+            continue
+        if name is None:
+            continue
+        ins = line.split(";")[0].strip()
+        if not ins or ins.startswith(".") or ins.endswith(":"):
+            continue
+        out[name].append(ins)
+    return out
+
+
+def reads_register(ins, reg):
+    """Does instruction text `ins` mention VGPR number `reg` (alone or inside a v[a:b] range)?"""
+    for m in re.finditer(r"\bv(\d+)\b", ins):
+        if int(m.group(1)) == reg:
+            return True
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", ins):
+        if int(m.group(1)) <= reg <= int(m.group(2)):
+            return True
+    return False
+
+
+def test_every_rsq_has_a_wait_state_before_its_consumer(isa):
+    fns = {n: body for n, body in functions(isa).items() if "step_kernel" in n}
+    assert len(fns) >= 16, sorted(fns)
+    total = 0
+    for name, body in fns.items():
+        for i, ins in enumerate(body):
+            if not ins.startswith("v_rsq_f32"):
+                continue
+            total += 1
+            dest = int(re.match(r"v_rsq_f32(?:_e\d+)?\s+v(\d+)", ins).group(1))
+            nxt = body[i + 1]
+            assert not (nxt.startswith("v_") and reads_register(nxt, dest)), \
+                f"{name}: `{ins}` is read by the very next instruction `{nxt}` (no wait state)"
+            # the shipped body: the slot is the s_setprio 0 that ends the raised-priority window
+            assert nxt.startswith("s_setprio 0"), f"{name}: expected s_setprio 0 after the rsq, found `{nxt}`"
+            assert body[i - 1].startswith("s_setprio 3"), f"{name}: rsq not issued at raised priority: `{body[i - 1]}`"
+    assert total >= 16 * 8, total
+
+
+def test_step_kernels_fit_the_occupancy_the_launch_bounds_promise(isa):
+    meta = re.findall(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)\n\s+\.sgpr_count:\s+(\d+)"
+                      r"(?:\n.*?)*?\n\s+\.vgpr_count:\s+(\d+)", isa)
+    step = [(n, int(scratch), int(sgpr), int(vgpr)) for n, scratch, sgpr, vgpr in meta if "step_kernel" in n]
+    assert len(step) >= 16
+    for name, scratch, sgpr, vgpr in step:
+        assert vgpr <= 64, f"{name}: {vgpr} VGPRs (> 64 halves the occupancy of a 1024-thread workgroup)"
+        assert scratch == 0, f"{name}: {scratch} bytes of scratch (spills)"
+        assert sgpr <= 102, f"{name}: {sgpr} SGPRs"
+    # the default (scalar-cache) route keeps the asm body's footprint: well under the limit
+    smem = [v for n, _, _, v in step if n.endswith("ELi1EEEvNS_10StepParamsE")]
+    assert smem and max(smem) <= 48, smem
+
+
+def test_interaction_body_is_the_ten_instruction_sequence(isa):
+    """One (source, receiver) interaction = v_pk_add, v_fma, v_fmac, s_setprio, v_rsq, s_setprio, 3 x v_mul, v_pk_fma
+    in their short encodings (the 8-byte VOP3 forms measured 11.6 % slower: DESIGN.md section 3)."""
+    body = next(b for n, b in functions(isa).items() if "step_kernelILi2ELi16ELi1E" in n)
+    want = ["v_pk_add_f32", "v_fma_f32", "v_fmac_f32", "s_setprio", "v_rsq_f32", "s_setprio", "v_mul_f32", "v_mul_f32",
+            "v_mul_f32", "v_pk_fma_f32"]
+    ops = [ins.split()[0] for ins in body]
+    hits = sum(1 for i in range(len(ops) - len(want) + 1) if ops[i:i + len(want)] == want)
+    assert hits >= 32, hits      # two unrolled 8-source groups x 2 receivers per lane, at least
+    assert not any(op.endswith("_e64") for op in ops if op.startswith(("v_mul_f32", "v_fmac_f32", "v_rsq_f32")))

@@ -38,7 +38,7 @@ def test_bench_multi_rank_control_flow_dry_run(world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29610 + world),
            os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--particles", "65536",
-           "--dry-run"]
+           "--extra-particles", "131072", "--dry-run"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -47,3 +47,39 @@ def test_bench_multi_rank_control_flow_dry_run(world):
     assert out["n_gpus"] == world and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "strong"
     assert out["unit"] == "interactions/s" and out["dtype"] == "f32" and "roofline" in out and "cpu_baseline" not in out
     assert f"N/{world}" in out["config"]["parallelism"]
+    # what the first real multi-GPU run must carry: the communicator's own rank count, the
+    # per-step all-gather and kernel times over the ranks, the cross-rank self-check, and config 5 from the same command
+    assert "rccl_nranks" in out and set(out["rccl"]) >= {"nranks_reported", "user_ranks", "devices", "version", "lib",
+                                                         "ranks_with_communicator", "first_gather_ms_rank0"}
+    for key in ("comm_ms_per_step", "kernel_ms_per_step"):
+        assert set(out[key]) == {"min", "max"}
+    assert out["self_check"]["ranks_agree"] is True          # every rank generated the same initial conditions
+    extra = out["extra_configs"]
+    assert [(e["overlap"], "N=65536" in e["workload"]) for e in extra] == [(1, True), (0, False), (1, False)]
+    assert all("N=131072" in e["workload"] for e in extra[1:])
+    for e in extra:
+        assert set(e) >= {"workload", "overlap", "steps", "ms_per_step", "steps_per_sec", "value", "unit",
+                          "kernel_ms_per_step", "comm_ms_per_step"}
+    assert out["roofline"]["traffic"] is None and "traffic_note" in out["roofline"]
+
+
+def test_bench_traffic_figure_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
+    """roofline.traffic comes from a committed PMC profile and must go null (with a note) once the kernel sources no
+    longer hash to what was profiled."""
+    import json
+    root = os.path.dirname(HERE)
+    sys.path.insert(0, root)
+    import bench
+    rec = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    assert set(rec) >= {"hbm_bytes_per_launch", "kernel_sources_sha256", "n", "source"}
+    value, note = bench.pmc_traffic(1 << 20)
+    if rec["kernel_sources_sha256"] == bench.kernel_sources_sha():
+        assert value == rec["hbm_bytes_per_launch"] and "from profiles/" in note
+    else:
+        assert value is None and note.startswith("stale")
+    monkeypatch.setattr(bench, "kernel_sources_sha", lambda: "0" * 64)
+    value, note = bench.pmc_traffic(1 << 20)
+    assert value is None and note.startswith("stale")
+    assert bench.pmc_traffic(12345)[0] is None
+    # N * (12 + 12 + 8 + 8) + 12 M read, N * 32 written, over two passes (DESIGN.md section 3)
+    assert bench.algorithmic_bytes_per_launch(1 << 20, 523884, 2) == ((1 << 20) * 72 + 523884 * 12) / 2

@@ -90,7 +90,11 @@ text = "\n".join(lines) + "\n"
 open(os.path.join(out_dir, f"{tag}_rocprof_summary.txt"), "w").write(text)
 json.dump(summary, open(os.path.join(out_dir, f"{tag}_pmc_summary.json"), "w"), indent=1)
 if "hbm_bytes_per_launch" in summary:
+    sys.path.insert(0, ROOT)
+    import bench  # kernel_sources_sha(): bench.py reports the figure only while the kernel sources still hash to this
     json.dump({"hbm_bytes_per_launch": summary["hbm_bytes_per_launch"], "source": f"profiles/{tag}_pmc_summary.json",
-               "note": "FETCH_SIZE*1024*2 (gfx950 correction) + WRITE_SIZE*1024, mean per step_kernel launch, N=2^20"},
+               "n": 1 << 20, "kernel_sources_sha256": bench.kernel_sources_sha(),
+               "note": "FETCH_SIZE*1024*2 (gfx950 correction) + WRITE_SIZE*1024, mean per step_kernel launch, N=2^20; "
+                       "run tools/summarize_profile.py on the same tree the profile was taken from"},
               open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
 print(text)
