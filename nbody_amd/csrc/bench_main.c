@@ -10,14 +10,21 @@
  * Extras the BASELINE.json configurations need:
  *   --n N          one size instead of the table (repeatable)
  *   --steps K      timed steps            (default 100)
- *   --warmup W     untimed steps          (default 10)
+ *   --warmup W     untimed steps          (default 10; 0 still runs one: it carries the upload)
  *   --dt DT        step size              (default 1.0, the reference's)
  *   --galaxies G   galaxies per universe  (default 2)
  *   --seed S       srand seed             (default 11037)
  *   --own-rng      draw the universes from MakeGalaxiesSeeded(seed + row) instead of libc rand()
  * and more columns: interactions/s = N * mass_len * steps / time per backend, and for the GPU the share of the
- * fp32 roofline that is (14 flop per interaction, 157.3 TFLOP/s).  Several GPUs are driven one process per GPU
- * (bench.py under torch.distributed.run, include/nbody_hip.h part 2), not from this single-process harness.
+ * fp32 roofline that is (14 flop per interaction, 157.3 TFLOP/s), then what the chip allows at THIS size:
+ *   GPU floor = N * mass_len / 5.3e12 interactions/s  (the rate the step kernel sustains at N = 2^20, i.e. the
+ *               instruction-mix bound of its 8 VALU instructions per interaction)
+ *             + kernels per step x 1.7 us              (dependent-launch floor inside a hipGraph on this box,
+ *               profiles/r01_ubench6_launch_floor.txt; a step is 1 kernel, or 2 when the sources are split)
+ *   %floor    = floor / measured: how close the step is to that bound.  Below N ~ 50 000 a launch cannot fill the
+ *               chip for long enough to amortise its latencies; the reference's SIZES[] (bench.c:38) all live there.
+ * Several GPUs are driven one process per GPU (bench.py under torch.distributed.run, include/nbody_hip.h part 2),
+ * not from this single-process harness.
  */
 #include <stdbool.h>
 #include <stdio.h>
@@ -27,6 +34,10 @@
 
 #include <galaxy.h>
 #include <nbody.h>
+#include <nbody_hip.h>
+
+#define LARGE_N_RATE 5.3e12       /* interactions/s of the step kernel at N = 2^20 (bench.py, BENCH_r01.json) */
+#define LAUNCH_FLOOR_US 1.7       /* per dependent kernel inside a hipGraph (profiles/r01_ubench6_launch_floor.txt) */
 
 typedef void (*UpdateFn)(World *, float, uint32_t);
 
@@ -38,7 +49,10 @@ static double seconds_now(void) {
 
 /* one warm-up call, one timed call; returns seconds per step */
 static double time_backend(World *w, UpdateFn update, float dt, uint32_t warmup, uint32_t steps) {
-    update(w, dt, warmup);
+    /* At least one untimed step always runs, also with --warmup 0: the first UpdateWorld_GPU call carries the
+     * upload and the first-touch device setup (stream, HBM buffers, page-locking the World's array), which are
+     * not part of a step.  A zero-step call cannot stand in: it is a no-op by contract (world.c:113). */
+    update(w, dt, warmup > 0 ? warmup : 1);
     const double t0 = seconds_now();
     update(w, dt, steps);
     const double t1 = seconds_now();
@@ -103,7 +117,7 @@ int main(int argc, char **argv) {
     if (use_cpu) printf("\t    CPU");
     if (use_gpu) printf("\t    GPU");
     if (use_cpu) printf("\t  CPU int/s");
-    if (use_gpu) printf("\t  GPU int/s\t GPU %%peak");
+    if (use_gpu) printf("\t  GPU int/s\t GPU %%peak\tfloor us\t   %%floor");
     printf("\n");
 
     for (uint32_t s = 0; s < n_sizes; s++) {
@@ -128,7 +142,18 @@ int main(int argc, char **argv) {
         if (use_cpu) printf("\t%11.3e", pairs / cpu_s);
         /* roofline column: 14 flop per interaction (reference op count, sim_cpu.c:169-188) against the
          * MI355X fp32 vector peak of 157.3 TFLOP/s -- the same convention as bench.py */
-        if (use_gpu) printf("\t%11.3e\t%9.1f", pairs / gpu_s, pairs / gpu_s * 14.0 / 157.3e12 * 100.0);
+        if (use_gpu) {
+            int k = 0, wv = 0, split = 1;
+            uint32_t groups = 0;
+            const uint32_t m = count_massive(ps, n);
+            /* passes: one launch per <= 3 MiB of (x, y, G*m) sources (pipeline.hip passes_for) */
+            const uint32_t passes = m ? (uint32_t)(((uint64_t)m * 12 + (3u << 20) - 1) / (3u << 20)) : 1;
+            nb_hip_plan_launch(n, (m + passes - 1) / passes, 256, &k, &wv, &split, &groups);
+            const double kernels = (double)passes * (split > 1 ? 2.0 : 1.0);
+            const double floor_us = pairs / LARGE_N_RATE * 1e6 + kernels * LAUNCH_FLOOR_US;
+            printf("\t%11.3e\t%9.1f\t%8.1f\t%9.1f", pairs / gpu_s, pairs / gpu_s * 14.0 / 157.3e12 * 100.0, floor_us,
+                   floor_us / (gpu_s * 1e6) * 100.0);
+        }
         printf("\n");
         fflush(stdout);
         free(ps);
