@@ -204,6 +204,12 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
+    # stdout carries exactly one line, the JSON: RCCL prints a version banner to stdout from native code, so the
+    # process' fd 1 is pointed at stderr for the duration and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     # multi-process GPU work on this pool needs dmabuf IPC; RCCL's own log goes to a per-rank file so that stdout
     # keeps the one JSON line (the library's watchdog prints the file's tail if a collective never completes)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -457,7 +463,8 @@ def main():
         out.update(extras)
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if dist is not None:
         dist.barrier()

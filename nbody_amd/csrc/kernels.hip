@@ -194,16 +194,49 @@ __device__ __forceinline__ void finish_receiver(const StepParams &p, uint32_t lo
 }
 
 // Second kernel of a split step: one thread per receiver adds the parts in part order and finishes.
+// The kernel is pure latency -- a handful of loads, a handful of adds, three stores -- and what it reads was just
+// written by other CUs (the parts) or other XCDs (acc, vel, pos), so every load is a 500-900 cycle trip to the
+// Infinity Cache or HBM.  Issued one after the other behind a loop with a run-time trip count they cost `split` + 2 such
+// trips in a row (measured: 4.0 us per launch at N = 10 000 / 5 parts, 5.0 us at 50 000 / 7 parts, of a 21 us step:
+// profiles/r02_mid_n_pmc.txt); issued all at once, before the first use, they cost one.  Unused slots re-read the last
+// part (always a valid address) and are dropped by a select, so the loads need no branch.
 __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
     const uint32_t logical = blockIdx.x * blockDim.x + threadIdx.x;
     if (logical >= p.n_recv) return;
+    const uint32_t i = receiver_slot(p, logical);
+    float2 part[MAX_SPLIT];
+#pragma unroll
+    for (uint32_t s = 0; s < (uint32_t)MAX_SPLIT; s++)
+        part[s] = p.parts[(size_t)(s < p.split ? s : p.split - 1) * p.n_recv + logical];
+    const bool carry = (p.flags & STEP_ACC_IN) != 0, integrate = (p.flags & STEP_NO_FINALIZE) == 0;
+    // clamped-to-valid addresses again: acc / vel / pos_in exist for every slot whatever the flags say
+    const float2 a0 = p.acc[i];
+    const float2 v0 = p.vel[i];
+    const float2 q0 = p.pos_in[i];
     float sx = 0.0f, sy = 0.0f;
-    for (uint32_t s = 0; s < p.split; s++) {
-        const float2 t = p.parts[(size_t)s * p.n_recv + logical];
-        sx = __fadd_rn(sx, t.x);
-        sy = __fadd_rn(sy, t.y);
+#pragma unroll
+    for (uint32_t s = 0; s < (uint32_t)MAX_SPLIT; s++) {
+        // same order and roundings as a sequential loop over the parts: 0 + p0 + p1 + ...
+        const float nx = __fadd_rn(sx, part[s].x), ny = __fadd_rn(sy, part[s].y);
+        sx = s < p.split ? nx : sx;
+        sy = s < p.split ? ny : sy;
     }
-    finish_receiver(p, logical, sx, sy);
+    float2 a = make_float2(sx, sy);
+    if (carry) {
+        a.x = __fadd_rn(a0.x, a.x);
+        a.y = __fadd_rn(a0.y, a.y);
+    }
+    p.acc[i] = a;
+    if (!integrate) return;
+    // semi-implicit Euler with the reference's roundings (finish_receiver): vel += acc*dt; pos += vel*dt
+    float2 v = v0, q = q0;
+    v.x = __fadd_rn(v.x, __fmul_rn(a.x, p.dt));
+    v.y = __fadd_rn(v.y, __fmul_rn(a.y, p.dt));
+    q.x = __fadd_rn(q.x, __fmul_rn(v.x, p.dt));
+    q.y = __fadd_rn(q.y, __fmul_rn(v.y, p.dt));
+    p.vel[i] = v;
+    p.pos_out[i] = q;
+    if (i < p.n_mirror) p.mirror[i] = q;
 }
 
 // Everything must stay within 64 VGPRs: a 1024-thread workgroup puts 4 waves on every SIMD, so 65 VGPRs (7 waves

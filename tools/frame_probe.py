@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""The reference GUI's call pattern (src/main.c:157-163,237-250): every frame UpdateWorld_GPU(world, PHYS_STEP, updates)
+then GetWorldParticles for drawing -- 6000 particles, 3 galaxies (main.c:13,44), `updates` = 1, 2, 4, 8 (the STEPS[]
+multiplier).  Wall time per frame through the include/nbody.h surface, hipGraph policy 0 / 1 / 2, and the same without
+the read-back."""
+import os, sys, time
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+import nbody_amd as nb
+frames = 300
+sizes = [int(x) for x in sys.argv[1:]] or [6000, 1000, 20000]
+for n in sizes:
+    ic = nb.make_galaxies(n, 3, seed=11037)
+    for updates in (1, 2, 4, 8):
+        row = []
+        for graph in ("0", "1", "2"):
+            os.environ["NB_HIP_GRAPH"] = graph          # read by CreateSimPipeline (the World owns its pipeline)
+            w = nb.World(ic)
+            for _ in range(5):
+                w.update_gpu(0.01, updates); w.particles()
+            t0 = time.perf_counter()
+            for _ in range(frames):
+                w.update_gpu(0.01, updates); w.particles()
+            full = (time.perf_counter() - t0) / frames * 1e6
+            t0 = time.perf_counter()
+            for _ in range(frames):
+                w.update_gpu(0.01, updates)
+            bare = (time.perf_counter() - t0) / frames * 1e6
+            w.close()
+            row.append(f"graph={graph}: {full:7.1f} us/frame ({bare:6.1f} without read-back)")
+        print(f"N={n:6d} updates={updates}: " + " | ".join(row), flush=True)
