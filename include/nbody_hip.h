@@ -136,7 +136,7 @@ int nb_hip_runtime_version(void);
  * particle array).  It is page-locked (hipHostRegister) when the pipeline first touches the GPU and released in
  * DestroySimPipeline, so the hand-over runs at PCIe speed instead of through pageable memory.  The array must stay
  * allocated until DestroySimPipeline or until this is called again (array = NULL forgets it).  Set/Get with any
- * other pointer keep working unchanged.
+ * other pointer keep working unchanged.  See the "readback" knob for what else the pipeline may do with it.
  */
 void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
 
@@ -155,6 +155,15 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
  *               per (length, ping-pong phase), patched when dt changes), 0 = plain stream launches, 2 (default) = a chain length runs as plain
  *               launches the first time it is asked for and as a hipGraph from the second time on (building a
  *               chain costs more than one replay saves)
+ *   "readback"  when the device state reaches the host array named by nb_hip_note_host_array: 0 = only when
+ *               GetSimulationData asks (merge kernel + D2H copy + wait), 1 = at the end of every blocking
+ *               PerformSimUpdate (the merge kernel is appended to the update's own submission and stores straight into
+ *               the page-locked array; the following GetSimulationData into that array returns at once), 2 (default) =
+ *               auto: eager once two updates in a row were each followed by a Get into the noted array (a frame loop:
+ *               reference src/main.c:157-163,237), lazy again as soon as an update follows an update.  Between an
+ *               eager PerformSimUpdate and the next GetSimulationData the noted array's contents are unspecified (old
+ *               or new state); the include/nbody.h surface never exposes that window (GetWorldParticles pulls first).
+ *   "timing"    1 (default) = bracket every chain with a HIP event pair (nb_hip_last_step_ms), 0 = do not
  *   "sharded_graph"  sharded pipelines: 1 = capture the {kernel, all-gather} x n chain into a hipGraph and replay
  *               it (non-overlapped step only); 0 = plain stream launches (default)
  *   "overlap"   sharded pipelines: 1 = split each step into own-shard / remote-shard kernels

@@ -190,6 +190,16 @@ void ensure_device() {
     int ord = g_requested_ordinal >= 0 ? g_requested_ordinal : 0;
     NB_ASSERT(ord < count, "device ordinal %d requested, %d visible", ord, count);
     ASSERT_HIP(hipSetDevice(ord), "hipSetDevice(%d)", ord);
+    // PerformSimUpdate is synchronous by contract (the reference blocks on its fence, sim_gpu.c:353) and interactive
+    // callers step a few thousand particles per frame: how fast the host notices completion is part of the step time.
+    // NB_HIP_WAIT=spin|yield|block picks the runtime's wait policy before the context exists; default: the runtime's.
+    if (const char *wp = getenv("NB_HIP_WAIT")) {
+        const unsigned flag = !strcmp(wp, "spin") ? hipDeviceScheduleSpin
+                              : !strcmp(wp, "yield") ? hipDeviceScheduleYield
+                              : !strcmp(wp, "block") ? hipDeviceScheduleBlockingSync
+                                                     : hipDeviceScheduleAuto;
+        if (hipSetDeviceFlags(flag) != hipSuccess) (void)hipGetLastError();  // context already live: keep its policy
+    }
     hipDeviceProp_t prop;
     ASSERT_HIP(hipGetDeviceProperties(&prop, ord), "hipGetDeviceProperties(%d)", ord);
     NB_ASSERT(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
@@ -292,6 +302,15 @@ struct SimPipeline {
     void *host_array = nullptr;  // caller's long-lived particle array (nb_hip_note_host_array), page-locked lazily
     size_t host_bytes = 0;
     bool host_pinned = false;
+    void *host_dev = nullptr;    // device-side address of the page-locked array (kernels store to it over PCIe)
+    // eager read-back (knob "readback"): in a frame loop -- every blocking update followed by a Get into the noted
+    // array -- the merge kernel of the NEXT Get is appended to the update's own submission and stores straight into the
+    // noted array, so the Get finds its data already there: one submission + one wait per frame instead of two
+    // (step + wait, then merge + D2H copy + wait).
+    int readback = 2;             // 0 never, 1 after every blocking update, 2 auto (after two update->Get pairs in a row)
+    bool host_current = false;    // the noted array already holds the device's latest state
+    uint32_t updates_since_get = 0, frame_streak = 0;
+    int timing = 1;               // record the ev_begin / ev_end pair around every chain (nb_hip_last_step_ms)
     float2 *parts = nullptr;    // split steps only: [split][n_real] partial sums
     uint32_t parts_cap = 0;     // float2 elements allocated in parts
     int cur = 0;             // pos[cur] is the latest state
@@ -326,6 +345,10 @@ namespace {
 
 constexpr uint32_t GRAPH_CHAIN_MAX = 64;  // longer requests replay an even-length chain
 constexpr size_t GRAPH_CACHE_MAX = 8;     // cached chains per pipeline; the least recently used one is evicted
+// graph = 2 (auto): chains shorter than this stay plain launches.  A hipGraphLaunch costs the host ~12 us more than
+// a few plain launches and a replayed node saves 1.5-2 us, so a graph pays from ~8 steps on
+// (profiles/r02_frame_loop_latency.txt: 2-step frames 33 -> 44 us with a graph, 8-step frames 104 -> 101 us).
+constexpr uint32_t GRAPH_AUTO_MIN_CHAIN = 8;
 
 void destroy_graph(StepGraph &g) {
     if (g.exec) ASSERT_HIP(hipGraphExecDestroy(g.exec), "hipGraphExecDestroy");
@@ -341,16 +364,23 @@ void unpin_host(SimPipeline *s) {
         // best effort: the array is the caller's; failing to unregister must not take the process down
         (void)hipHostUnregister(s->host_array);
         s->host_pinned = false;
+        s->host_dev = nullptr;
+        s->host_current = false;
     }
 }
 
 void pin_host(SimPipeline *s) {
     if (s->host_pinned || s->host_array == nullptr || s->host_bytes == 0) return;
     // page-lock the caller's array so that H2D / D2H run at PCIe speed instead of through a pageable bounce
-    if (hipHostRegister(s->host_array, s->host_bytes, hipHostRegisterDefault) == hipSuccess)
+    if (hipHostRegister(s->host_array, s->host_bytes, hipHostRegisterMapped | hipHostRegisterPortable) == hipSuccess) {
         s->host_pinned = true;
-    else
+        if (hipHostGetDevicePointer(&s->host_dev, s->host_array, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            s->host_dev = nullptr;  // no zero-copy stores then: Get keeps using the D2H copy
+        }
+    } else {
         (void)hipGetLastError();  // not fatal: copies stay correct, only slower
+    }
 }
 
 // Make room for one more cached chain: the least recently used one goes (a frame loop with a varying chain length
@@ -633,7 +663,7 @@ StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchS
 
 void enqueue_single(SimPipeline *s, uint32_t n, float dt) {
     const nb::LaunchShape sh = resolve_shape(s);
-    if (!s->use_graph || n == 1) {
+    if (!s->use_graph || n == 1 || (s->use_graph == 2 && n < GRAPH_AUTO_MIN_CHAIN)) {
         for (uint32_t i = 0; i < n; i++) {
             launch_step(s, sh, whole_step(s, s->cur, dt), s->stream);
             s->cur ^= 1;
@@ -807,13 +837,14 @@ void enqueue_steps(SimPipeline *s, uint32_t n, float dt) {
     s->kernel_iv.clear();
     s->comm_iv.clear();
     s->detail_steps = 0;
-    ASSERT_HIP(hipEventRecord(s->ev_begin, s->stream), "record begin");
+    s->host_current = false;
+    if (s->timing) ASSERT_HIP(hipEventRecord(s->ev_begin, s->stream), "record begin");
     if (!s->sharded)
         enqueue_single(s, n, dt);
     else
         enqueue_sharded(s, n, dt);
-    ASSERT_HIP(hipEventRecord(s->ev_end, s->stream), "record end");
-    s->timed = true;
+    if (s->timing) ASSERT_HIP(hipEventRecord(s->ev_end, s->stream), "record end");
+    s->timed = s->timing != 0;
     s->timed_launches = (s->sharded && s->overlap) ? 2 * n : n * passes_for(s, whole_step(s, s->cur, dt));
     s->timed_finish_launches = s->last_shape.split > 1 ? s->timed_launches : 0;
     s->data.dt = dt;
@@ -921,6 +952,10 @@ SimPipeline *CreateSimPipeline(WorldData data) {
     if (ps) s->want_passes = atoi(ps);
     const char *sp = getenv("NB_HIP_SPLIT");
     if (sp) s->want_split = atoi(sp);
+    const char *rb = getenv("NB_HIP_READBACK");
+    if (rb) s->readback = atoi(rb) < 0 || atoi(rb) > 2 ? 2 : atoi(rb);
+    const char *tm = getenv("NB_HIP_TIMING");
+    if (tm) s->timing = atoi(tm) ? 1 : 0;
     const char *gr = getenv("NB_HIP_GRAPH");
     if (gr) s->use_graph = atoi(gr) < 0 || atoi(gr) > 2 ? 2 : atoi(gr);
     return s;
@@ -1067,6 +1102,8 @@ void SetSimulationData(SimPipeline *s, const Particle *ps) {
     hipStream_t st = s->stream;
     ASSERT_HIP(hipMemcpyAsync(s->aos, ps, (size_t)N * sizeof(Particle), hipMemcpyHostToDevice, st), "H2D of %u particles", N);
     s->cur = 0;
+    s->host_current = false;
+    s->updates_since_get = 0;
     if (!s->sharded) {
         nb::launch_split(st, s->aos, 0, N, s->pos[0], s->vel, s->acc, s->radius, s->mass, 0);
         nb::launch_make_gm(st, s->mass, s->src_gm, M);
@@ -1091,6 +1128,18 @@ void GetSimulationData(const SimPipeline *cs, Particle *ps) {
     NB_ASSERT(s->on_device, "GetSimulationData before SetSimulationData");
     const uint32_t N = s->data.total_len;
     if (N == 0) return;
+    if (!s->sharded) {
+        if (ps == s->host_array && s->updates_since_get == 1)
+            s->frame_streak++;  // one update, then a Get into the noted array: a frame
+        else
+            s->frame_streak = 0;
+        s->updates_since_get = 0;
+        if (s->host_current) {
+            // the update's own submission already stored this state into the noted array (eager read-back)
+            if (ps != s->host_array) memcpy(ps, s->host_array, (size_t)N * sizeof(Particle));
+            return;
+        }
+    }
     use_device();
     hipStream_t st = s->stream;
     if (!s->sharded) {
@@ -1143,6 +1192,17 @@ void nb_hip_sync(SimPipeline *s) {
 
 void PerformSimUpdate(SimPipeline *s, uint32_t n, float dt) {
     nb_hip_step_async(s, n, dt);
+    if (n > 0 && s->on_device && !s->sharded && s->slots > 0) {
+        // an update that follows an update (no Get in between) ends a frame-loop streak
+        if (s->updates_since_get > 0) s->frame_streak = 0;
+        s->updates_since_get++;
+        const bool eager = s->host_dev != nullptr && s->host_bytes >= (size_t)s->data.total_len * sizeof(Particle) &&
+                           (s->readback == 1 || (s->readback == 2 && s->frame_streak >= 2));
+        if (eager) {
+            nb::launch_merge(s->stream, s->host_dev, 0, s->data.total_len, s->pos[s->cur], s->vel, s->acc, s->radius, s->mass, 0);
+            s->host_current = true;  // true once the wait below returns
+        }
+    }
     nb_hip_sync(s);
 }
 
@@ -1253,6 +1313,14 @@ int nb_hip_configure(SimPipeline *s, const char *key, int value) {
         NB_ASSERT(value >= 0 && value <= 64, "passes must be 0 (auto) .. 64, got %d", value);
         old = s->want_passes;
         s->want_passes = value;
+    } else if (!strcmp(key, "readback")) {
+        NB_ASSERT(value >= 0 && value <= 2, "readback must be 0 (lazy), 1 (eager) or 2 (auto), got %d", value);
+        old = s->readback;
+        s->readback = value;
+        s->frame_streak = 0;
+    } else if (!strcmp(key, "timing")) {
+        old = s->timing;
+        s->timing = value ? 1 : 0;
     } else if (!strcmp(key, "sharded_graph")) {
         old = s->sharded_graph;
         s->sharded_graph = value ? 1 : 0;

@@ -157,6 +157,63 @@ def test_read_back_every_frame_equals_one_call(golden):
     assert a.tobytes() == run(part, m, 5, 0.01).tobytes()
 
 
+@pytest.mark.parametrize("readback", [0, 1, 2])
+def test_frame_loop_read_back_modes_give_the_same_frames(golden, readback):
+    """The GUI's pattern (reference src/main.c:157-163,237): UpdateWorld_GPU then GetWorldParticles every frame.  With
+    readback = 1 / 2 (auto) the merge kernel rides in the update's submission and stores straight into the World's
+    page-locked array; every frame must equal the lazy path's, also when the pattern breaks (two updates in a row,
+    a CPU step in between, a Get into a foreign buffer through the seam)."""
+    ic = golden("ic_1024.bin")
+    env_old = os.environ.get("NB_HIP_READBACK")
+    frames = {}
+    for mode in (0, readback):
+        os.environ["NB_HIP_READBACK"] = str(mode)
+        try:
+            w = nb.World(ic)
+            out = []
+            for f in range(5):
+                w.update_gpu(0.01, 1 + (f & 1))
+                out.append(w.particles())
+            w.update_gpu(0.01, 1)
+            w.update_gpu(0.01, 2)          # update after update: the streak ends, next Get is lazy again
+            out.append(w.particles())
+            w.update_cpu(0.01, 1)          # pulls (nothing stale), steps on the CPU, marks the host newer
+            w.update_gpu(0.01, 1)          # re-upload, step
+            out.append(w.particles())
+            for f in range(3):
+                w.update_gpu(0.005, 3)
+                out.append(w.particles())
+            w.close()
+        finally:
+            if env_old is None:
+                os.environ.pop("NB_HIP_READBACK", None)
+            else:
+                os.environ["NB_HIP_READBACK"] = env_old
+        frames[mode] = out
+    for a, b in zip(frames[0], frames[readback]):
+        assert a.tobytes() == b.tobytes()
+
+
+def test_eager_read_back_through_the_seam_with_a_foreign_buffer(golden):
+    import ctypes as C
+    part, m = ob.partition(golden("ic_333.bin"))
+    home = part.copy()                                   # the array the pipeline is told about
+    sim = nb.SimPipeline(333, m)
+    nb.hip_lib().nb_hip_note_host_array(sim._h, home.ctypes.data, home.nbytes)
+    sim.configure(readback=1)
+    sim.set_data(part)
+    sim.update(2, 0.01)                                  # eager: `home` now holds the state
+    want = run(part, m, 2, 0.01)
+    assert home.tobytes() == want.tobytes()
+    assert sim.get_data().tobytes() == want.tobytes()    # Get into another buffer: host copy of the noted array
+    sim.step_async(1, 0.01)                              # async steps never write the host array
+    sim.sync()
+    assert home.tobytes() == want.tobytes()
+    assert sim.get_data().tobytes() == run(part, m, 3, 0.01).tobytes()
+    nb.hip_lib().nb_hip_note_host_array(sim._h, None, 0)
+    sim.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # step chains: hipGraph vs plain launches, phases, dt patching
 # ---------------------------------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ for n in sizes:
     ic = nb.make_galaxies(n, 3, seed=11037)
     for updates in (1, 2, 4, 8):
         row = []
-        for graph in ("0", "1", "2"):
+        for graph in ("0", "2"):
             os.environ["NB_HIP_GRAPH"] = graph          # read by CreateSimPipeline (the World owns its pipeline)
             w = nb.World(ic)
             for _ in range(5):
@@ -28,4 +28,5 @@ for n in sizes:
             bare = (time.perf_counter() - t0) / frames * 1e6
             w.close()
             row.append(f"graph={graph}: {full:7.1f} us/frame ({bare:6.1f} without read-back)")
-        print(f"N={n:6d} updates={updates}: " + " | ".join(row), flush=True)
+        tag = " ".join(f"{k[7:].lower()}={os.environ[k]}" for k in ("NB_HIP_READBACK", "NB_HIP_TIMING", "NB_HIP_WAIT") if k in os.environ)
+        print(f"[{tag or 'defaults'}] N={n:6d} updates={updates}: " + " | ".join(row), flush=True)
