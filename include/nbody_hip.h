@@ -95,7 +95,8 @@ void nb_hip_sync(SimPipeline *sim);
 /*
  * Device time, in milliseconds, of the force+integrate kernels of the most
  * recent PerformSimUpdate / nb_hip_step_async (HIP events recorded on the
- * launch stream around the step chain; waits for them).  *launches receives the
+ * launch stream around the step chain; waits for them).  Needs the "timing"
+ * knob (nb_hip_configure(sim, "timing", 1)); returns 0 without it.  *launches receives the
  * number of step-kernel launches those events bracket.
  */
 double nb_hip_last_step_ms(SimPipeline *sim, uint32_t *launches);
@@ -154,7 +155,8 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
  *   "graph"     how PerformSimUpdate(n > 1) runs its chain: 1 = always as a hipGraph (built on first use, cached,
  *               per (length, ping-pong phase), patched when dt changes), 0 = plain stream launches, 2 (default) = a chain length runs as plain
  *               launches the first time it is asked for and as a hipGraph from the second time on (building a
- *               chain costs more than one replay saves)
+ *               chain costs more than one replay saves), and chains shorter than 16 steps always do (a graph launch
+ *               costs the host ~12 us more than a few plain launches)
  *   "readback"  when the device state reaches the host array named by nb_hip_note_host_array: 0 = only when
  *               GetSimulationData asks (merge kernel + D2H copy + wait), 1 = at the end of every blocking
  *               PerformSimUpdate (the merge kernel is appended to the update's own submission and stores straight into
@@ -163,7 +165,8 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
  *               reference src/main.c:157-163,237), lazy again as soon as an update follows an update.  Between an
  *               eager PerformSimUpdate and the next GetSimulationData the noted array's contents are unspecified (old
  *               or new state); the include/nbody.h surface never exposes that window (GetWorldParticles pulls first).
- *   "timing"    1 (default) = bracket every chain with a HIP event pair (nb_hip_last_step_ms), 0 = do not
+ *   "timing"    1 = bracket every chain with a HIP event pair so that nb_hip_last_step_ms can answer, 0 (default) =
+ *               do not (the two records cost a frame loop 3-7 us per call)
  *   "sharded_graph"  sharded pipelines: 1 = capture the {kernel, all-gather} x n chain into a hipGraph and replay
  *               it (non-overlapped step only); 0 = plain stream launches (default)
  *   "overlap"   sharded pipelines: 1 = split each step into own-shard / remote-shard kernels

@@ -174,6 +174,7 @@ class SimPipeline:
             self._h = L.CreateSimPipeline(wd)
         self.total_len, self.mass_len = total_len, mass_len
         self.rank, self.nranks = rank, nranks
+        self.configure(timing=1)   # tooling wants last_step_ms(); the C default is off (it costs a frame loop 3-7 us)
 
     def close(self):
         if self._h:
@@ -257,7 +258,7 @@ class LocalShardGroup:
             m = SimPipeline.__new__(SimPipeline)
             m._h = self._arr[r]
             m.total_len, m.mass_len, m.rank, m.nranks = total_len, mass_len, r, nranks
-            m.configure(**knobs)
+            m.configure(timing=1, **knobs)
             self.members.append(m)
 
     def set_data(self, particles):

@@ -117,7 +117,7 @@ int main(int argc, char **argv) {
     if (use_cpu) printf("\t    CPU");
     if (use_gpu) printf("\t    GPU");
     if (use_cpu) printf("\t  CPU int/s");
-    if (use_gpu) printf("\t  GPU int/s\t GPU %%peak\tfloor us\t   %%floor");
+    if (use_gpu) printf("\t  GPU int/s\t GPU %%peak\t  GPU us\tfloor us\t   %%floor");
     printf("\n");
 
     for (uint32_t s = 0; s < n_sizes; s++) {
@@ -151,8 +151,8 @@ int main(int argc, char **argv) {
             nb_hip_plan_launch(n, (m + passes - 1) / passes, 256, &k, &wv, &split, &groups);
             const double kernels = (double)passes * (split > 1 ? 2.0 : 1.0);
             const double floor_us = pairs / LARGE_N_RATE * 1e6 + kernels * LAUNCH_FLOOR_US;
-            printf("\t%11.3e\t%9.1f\t%8.1f\t%9.1f", pairs / gpu_s, pairs / gpu_s * 14.0 / 157.3e12 * 100.0, floor_us,
-                   floor_us / (gpu_s * 1e6) * 100.0);
+            printf("\t%11.3e\t%9.1f\t%8.2f\t%8.2f\t%9.1f", pairs / gpu_s, pairs / gpu_s * 14.0 / 157.3e12 * 100.0, gpu_s * 1e6,
+                   floor_us, floor_us / (gpu_s * 1e6) * 100.0);
         }
         printf("\n");
         fflush(stdout);

@@ -310,7 +310,9 @@ struct SimPipeline {
     int readback = 2;             // 0 never, 1 after every blocking update, 2 auto (after two update->Get pairs in a row)
     bool host_current = false;    // the noted array already holds the device's latest state
     uint32_t updates_since_get = 0, frame_streak = 0;
-    int timing = 1;               // record the ev_begin / ev_end pair around every chain (nb_hip_last_step_ms)
+    // record the ev_begin / ev_end pair around every chain (nb_hip_last_step_ms).  Off unless asked for: the two
+    // records cost an interactive caller 3-7 us per call (profiles/r02_frame_loop_latency.txt).
+    int timing = 0;
     float2 *parts = nullptr;    // split steps only: [split][n_real] partial sums
     uint32_t parts_cap = 0;     // float2 elements allocated in parts
     int cur = 0;             // pos[cur] is the latest state
@@ -346,9 +348,9 @@ namespace {
 constexpr uint32_t GRAPH_CHAIN_MAX = 64;  // longer requests replay an even-length chain
 constexpr size_t GRAPH_CACHE_MAX = 8;     // cached chains per pipeline; the least recently used one is evicted
 // graph = 2 (auto): chains shorter than this stay plain launches.  A hipGraphLaunch costs the host ~12 us more than
-// a few plain launches and a replayed node saves 1.5-2 us, so a graph pays from ~8 steps on
-// (profiles/r02_frame_loop_latency.txt: 2-step frames 33 -> 44 us with a graph, 8-step frames 104 -> 101 us).
-constexpr uint32_t GRAPH_AUTO_MIN_CHAIN = 8;
+// a few plain launches and a replayed node saves 1-2 us, so a graph pays from a dozen steps on
+// (profiles/r02_frame_loop_latency.txt: 2-step frames 33 -> 44 us with a graph, 8-step frames still 98 -> 102 us).
+constexpr uint32_t GRAPH_AUTO_MIN_CHAIN = 16;
 
 void destroy_graph(StepGraph &g) {
     if (g.exec) ASSERT_HIP(hipGraphExecDestroy(g.exec), "hipGraphExecDestroy");

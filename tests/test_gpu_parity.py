@@ -228,36 +228,44 @@ def test_graph_chain_equals_plain_launches(golden, n_steps):
 
 @pytest.mark.parametrize("graph", [1, 2])
 def test_split_calls_and_odd_phases(golden, graph):
-    # graph = 2 (the default): a chain length runs as plain launches once, as a cached hipGraph from then on
+    # graph = 2 (the default): chains of 16+ steps run as plain launches once, as a cached hipGraph from then on;
+    # shorter ones always as plain launches
     part, m = ob.partition(golden("ic_333.bin"))
-    want = run(part, m, 18, 0.01, graph=0)
+    calls = (3, 3, 1, 5, 3, 3, 17, 17, 16, 17, 17)   # same chain lengths reused on the other ping-pong phase
+    want = run(part, m, sum(calls), 0.01, graph=0)
     sim = nb.SimPipeline(333, m)
     sim.configure(graph=graph)
     sim.set_data(part)
-    for n in (3, 3, 1, 5, 3, 3):       # same chain length reused on the other ping-pong phase
+    for n in calls:
         sim.update(n, 0.01)
     got = sim.get_data()
+    stats = sim.graph_stats()
     sim.close()
     assert got.tobytes() == want.tobytes()
+    # always: (3, both phases), (5, 1), (17, both phases), (16, 0); auto: only 17 on both phases -- 16 ran once, as
+    # plain launches, and the short chains never become graphs
+    assert stats["cached"] == (6 if graph == 1 else 2)
 
 
 @pytest.mark.parametrize("graph", [1, 2])
 def test_dt_change_patches_the_cached_chain(golden, graph):
     part, m = ob.partition(golden("ic_333.bin"))
+    n = 4 if graph == 1 else 16  # auto mode keeps chains shorter than 16 steps as plain launches
     sim = nb.SimPipeline(333, m)
     sim.configure(graph=graph)
     sim.set_data(part)
-    sim.update(4, 0.01)
-    sim.update(4, 0.005)         # same n, dt halved: kernel-node parameters are rewritten
-    sim.update(4, 0.01)
-    sim.update(4, 0.0025)
+    sim.update(n, 0.01)
+    sim.update(n, 0.005)         # same n, dt halved: kernel-node parameters are rewritten
+    sim.update(n, 0.01)
+    sim.update(n, 0.0025)
     got = sim.get_data()
+    assert sim.graph_stats()["patches"] == (3 if graph == 1 else 2)   # auto: the first call ran as plain launches
     sim.close()
     ref = nb.SimPipeline(333, m)
     ref.configure(graph=0)
     ref.set_data(part)
     for dt in (0.01, 0.005, 0.01, 0.0025):
-        ref.update(4, dt)
+        ref.update(n, dt)
     want = ref.get_data()
     ref.close()
     assert got.tobytes() == want.tobytes()
