@@ -165,6 +165,8 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
  *               reference src/main.c:157-163,237), lazy again as soon as an update follows an update.  Between an
  *               eager PerformSimUpdate and the next GetSimulationData the noted array's contents are unspecified (old
  *               or new state); the include/nbody.h surface never exposes that window (GetWorldParticles pulls first).
+ *   "zero_copy_upload"  1 (default) = SetSimulationData from the noted, page-locked array lets the split kernel read the
+ *               records over PCIe itself (one launch); 0 = DMA copy into device staging, then the kernel
  *   "timing"    1 = bracket every chain with a HIP event pair so that nb_hip_last_step_ms can answer, 0 (default) =
  *               do not (the two records cost a frame loop 3-7 us per call)
  *   "sharded_graph"  sharded pipelines: 1 = capture the {kernel, all-gather} x n chain into a hipGraph and replay

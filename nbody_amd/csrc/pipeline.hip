@@ -308,6 +308,7 @@ struct SimPipeline {
     // noted array, so the Get finds its data already there: one submission + one wait per frame instead of two
     // (step + wait, then merge + D2H copy + wait).
     int readback = 2;             // 0 never, 1 after every blocking update, 2 auto (after two update->Get pairs in a row)
+    int zero_copy_upload = 1;     // SetSimulationData from the noted array: the split kernel reads host memory directly
     bool host_current = false;    // the noted array already holds the device's latest state
     uint32_t updates_since_get = 0, frame_streak = 0;
     // record the ev_begin / ev_end pair around every chain (nb_hip_last_step_ms).  Off unless asked for: the two
@@ -956,6 +957,8 @@ SimPipeline *CreateSimPipeline(WorldData data) {
     if (sp) s->want_split = atoi(sp);
     const char *rb = getenv("NB_HIP_READBACK");
     if (rb) s->readback = atoi(rb) < 0 || atoi(rb) > 2 ? 2 : atoi(rb);
+    const char *zc = getenv("NB_HIP_ZERO_COPY_UPLOAD");
+    if (zc) s->zero_copy_upload = atoi(zc) ? 1 : 0;
     const char *tm = getenv("NB_HIP_TIMING");
     if (tm) s->timing = atoi(tm) ? 1 : 0;
     const char *gr = getenv("NB_HIP_GRAPH");
@@ -1102,12 +1105,17 @@ void SetSimulationData(SimPipeline *s, const Particle *ps) {
     const uint32_t N = s->data.total_len, M = s->data.mass_len;
     if (N == 0) return;
     hipStream_t st = s->stream;
-    ASSERT_HIP(hipMemcpyAsync(s->aos, ps, (size_t)N * sizeof(Particle), hipMemcpyHostToDevice, st), "H2D of %u particles", N);
     s->cur = 0;
     s->host_current = false;
     s->updates_since_get = 0;
+    // The noted, page-locked array is readable from the device: the split kernel pulls the records over PCIe itself
+    // (one launch) instead of a DMA copy into the device staging followed by the kernel (two submissions' latency).
+    const bool zero_copy = !s->sharded && ps == s->host_array && s->host_dev != nullptr && s->zero_copy_upload &&
+                           s->host_bytes >= (size_t)N * sizeof(Particle);
+    if (!zero_copy)
+        ASSERT_HIP(hipMemcpyAsync(s->aos, ps, (size_t)N * sizeof(Particle), hipMemcpyHostToDevice, st), "H2D of %u particles", N);
     if (!s->sharded) {
-        nb::launch_split(st, s->aos, 0, N, s->pos[0], s->vel, s->acc, s->radius, s->mass, 0);
+        nb::launch_split(st, zero_copy ? s->host_dev : s->aos, 0, N, s->pos[0], s->vel, s->acc, s->radius, s->mass, 0);
         nb::launch_make_gm(st, s->mass, s->src_gm, M);
     } else {
         const NbShardPlan &pl = s->plan;
@@ -1320,6 +1328,9 @@ int nb_hip_configure(SimPipeline *s, const char *key, int value) {
         old = s->readback;
         s->readback = value;
         s->frame_streak = 0;
+    } else if (!strcmp(key, "zero_copy_upload")) {
+        old = s->zero_copy_upload;
+        s->zero_copy_upload = value ? 1 : 0;
     } else if (!strcmp(key, "timing")) {
         old = s->timing;
         s->timing = value ? 1 : 0;

@@ -194,6 +194,27 @@ def test_frame_loop_read_back_modes_give_the_same_frames(golden, readback):
         assert a.tobytes() == b.tobytes()
 
 
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_zero_copy_upload_equals_the_dma_upload(golden, n, monkeypatch):
+    """SetSimulationData from the World's page-locked array: the split kernel reads the records over PCIe itself
+    (default) or after a DMA copy into device staging (NB_HIP_ZERO_COPY_UPLOAD=0) -- same bytes either way, also
+    when the CPU stepper dirtied the array in between (reference world.c:76-81,99-118 protocol)."""
+    ic = golden(f"ic_{n}.bin")
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NB_HIP_ZERO_COPY_UPLOAD", mode)
+        w = nb.World(ic)
+        w.update_gpu(0.01, 2)
+        w.update_cpu(0.01, 1)
+        w.update_gpu(0.01, 1)       # re-upload of the CPU-stepped array
+        a = w.particles()
+        w.update_cpu(0.01, 0)
+        w.update_gpu(0.01, 3)
+        outs.append((a, w.particles()))
+        w.close()
+    assert outs[0][0].tobytes() == outs[1][0].tobytes() and outs[0][1].tobytes() == outs[1][1].tobytes()
+
+
 def test_eager_read_back_through_the_seam_with_a_foreign_buffer(golden):
     import ctypes as C
     part, m = ob.partition(golden("ic_333.bin"))
