@@ -3,8 +3,8 @@
  *
  * Restates the generator of the reference's src/lib/galaxy.c:31-221 so that,
  * under the same libc rand() stream, it produces the same particles bit for bit
- * (tests/test_galaxy.py checks it against the reference's compiled galaxy.c and
- * against tests/golden/ic_*.bin).  That requires drawing random numbers in the
+ * (tests/test_world_cpu.py::test_make_galaxies_bit_exact_with_compiled_reference checks it
+ * against the reference's compiled galaxy.c and against tests/golden/ic_*.bin).  That requires drawing random numbers in the
  * same order and rounding each expression the same way; the phases are:
  *
  *   1. sizes      galaxy g < G-1 takes rand % (1 + remaining) extra particles on

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): everything profiles/<tag>_* is made from, except the rocprofv3 passes
+# (tools/profile.sh, tools/profile_mid_n.sh).  usage: tools/collect_round.sh r02
+set -u
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out
+cd $R
+python -m pytest tests -m gpu -q > $O/${TAG}_pytest_gpu.txt 2>&1; echo "pytest rc=$?"
+python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"
+NB_HIP_FORCE_SHARDED=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
+    bench.py --gpus 1 --steps 10 --warmup 2 > $O/${TAG}_rehearsal_1rank.json 2> $O/${TAG}_rehearsal_1rank.err; echo "rehearsal rc=$?"
+{
+  echo "== nbody_amd/lib/nbody-bench (reference harness defaults: srand(11037), 10 warm-up + 100 steps, dt = 1; us/step), MI355X box, OMP_NUM_THREADS=16 =="
+  OMP_NUM_THREADS=16 ./nbody_amd/lib/nbody-bench
+  echo
+  echo "== oracle/_ref/nbody-bench-ref: the reference's own src/bench.c + src/lib/world.c + sim_cpu.c + galaxy.c, linked against libnbody_hip.so =="
+  OMP_NUM_THREADS=16 ./oracle/_ref/nbody-bench-ref
+} > $O/${TAG}_nbody_bench_tables.txt 2>&1; echo "tables rc=$?"
+{
+  echo "== tools/frame_probe.py: the reference GUI's frame loop through include/nbody.h (300 frames each), defaults =="
+  python tools/frame_probe.py 6000 1000 100000
+  echo "== the same with round 1's behaviour: lazy read-back, timing events on every call, DMA upload =="
+  NB_HIP_READBACK=0 NB_HIP_TIMING=1 NB_HIP_ZERO_COPY_UPLOAD=0 python tools/frame_probe.py 6000 1000 100000
+  echo "== one knob at a time, N = 6000 =="
+  NB_HIP_READBACK=0 python tools/frame_probe.py 6000
+  NB_HIP_TIMING=1 python tools/frame_probe.py 6000
+  NB_HIP_ZERO_COPY_UPLOAD=0 python tools/frame_probe.py 6000
+  NB_HIP_WAIT=spin python tools/frame_probe.py 6000
+  echo "== hipGraph chains in a frame loop: graph policy 0 (never) / 1 (always) / 2 (auto: 16+ steps, from the second use) =="
+  for g in 0 1 2; do NB_FRAME_UPDATES=2,8,16,32 NB_HIP_GRAPH=$g NB_HIP_READBACK=0 python tools/frame_probe.py 6000 | sed "s/^/[graph knob $g] /"; done
+} > $O/${TAG}_frame_loop_latency.txt 2>&1; echo "frame rc=$?"
+python tools/odd_chain_probe.py > $O/${TAG}_odd_chain_probe.txt 2>&1; echo "odd rc=$?"

@@ -11,10 +11,9 @@ frames = 300
 sizes = [int(x) for x in sys.argv[1:]] or [6000, 1000, 20000]
 for n in sizes:
     ic = nb.make_galaxies(n, 3, seed=11037)
-    for updates in (1, 2, 4, 8):
+    for updates in [int(x) for x in os.environ.get("NB_FRAME_UPDATES", "1,2,4,8").split(",")]:
         row = []
-        for graph in ("2",):
-            os.environ["NB_HIP_GRAPH"] = graph          # read by CreateSimPipeline (the World owns its pipeline)
+        for graph in (os.environ.get("NB_HIP_GRAPH", "2"),):   # read by CreateSimPipeline (the World owns its pipeline)
             w = nb.World(ic)
             for _ in range(5):
                 w.update_gpu(0.01, updates); w.particles()
