@@ -186,6 +186,10 @@ def main():
                     help="particles (default 2^20, the size the metric is quoted on); not --n: torchrun claims that prefix")
     ap.add_argument("--extra-particles", dest="n5", type=int, default=N_CONFIG5,
                     help="size of the second sharded workload under extra_configs (default 2^22 = BASELINE.json config 5)")
+    ap.add_argument("--transport", choices=("rccl", "host"), default="rccl",
+                    help="N > 1: rccl = in-stream ncclAllGather (the product path); host = the library's caller-supplied "
+                         "transport over torch.distributed gloo (host-staged, slow): lets several ranks share ONE GPU to "
+                         "rehearse the multi-process flow where RCCL refuses duplicate devices")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="headline leg only: no repeats / alt_lds (1 GPU), no self_check / extra_configs (N GPUs)")
@@ -254,6 +258,26 @@ def main():
             raw = bytearray(buf.numpy().tobytes())
         assert len(raw) == nb.UNIQUE_ID_BYTES
         return bytes(raw)
+
+    gloo_gather = None
+    if args.transport == "host" and sharded:
+        def gloo_gather(rows, r, n):
+            """In-place all-gather of host rows over gloo (rows[r] is filled on entry)."""
+            if dist is None:
+                return
+            mine = torch.from_numpy(rows[r].copy())
+            parts = [torch.empty_like(mine) for _ in range(n)]
+            dist.all_gather(parts, mine)
+            for q in range(n):
+                if q != r:
+                    rows[q] = parts[q].numpy()
+
+    def make_sim(n_, m_):
+        if not sharded:
+            return nb.SimPipeline(n_, m_)
+        if gloo_gather is not None:
+            return nb.SimPipeline(n_, m_, rank=rank, nranks=world, allgather=gloo_gather)
+        return nb.SimPipeline(n_, m_, rank=rank, nranks=world, unique_id=new_unique_id())
 
     if not args.dry_run:
         ndev = nb.device_count()
@@ -334,7 +358,7 @@ def main():
                 ]
         runtime = None
     else:
-        sim = nb.SimPipeline(n, mass_len, rank=rank, nranks=world, unique_id=new_unique_id() if sharded else None)
+        sim = make_sim(n, mass_len)
         if not sharded:
             sim.configure(graph=1)   # the K-step chain runs as a hipGraph on its first use, built inside the timed call
         sim.set_data(part)           # H2D + SoA split: outside the timed region
@@ -376,7 +400,7 @@ def main():
                 sim = None
                 # BASELINE.json config 5: N = 2^22, plain and overlapped (own communicator: a second ncclCommInitRank)
                 part5, m5 = make_workload(args.n5)
-                sim5 = nb.SimPipeline(part5.shape[0], m5, rank=rank, nranks=world, unique_id=new_unique_id())
+                sim5 = make_sim(part5.shape[0], m5)
                 sim5.set_data(part5)
                 for ov in (0, 1):
                     sim5.configure(overlap=ov)
@@ -450,7 +474,8 @@ def main():
                             f"{', massless half given NP_R_TO_M(radius) mass (all-massive N^2 run)' if args.all_massive else ''}"
                             f", partitioned; N={n}, mass_len={mass_len}, "
                             f"dt={DT}; {n * mass_len:.4g} interactions/step; one PerformSimUpdate({args.steps}) call",
-                "parallelism": f"receivers sharded N/{world} per GPU, all-gather of source positions per step"
+                "parallelism": (f"receivers sharded N/{world} per GPU, all-gather of source positions per step"
+                                + (" over the caller-supplied HOST transport (gloo; rehearsal, not RCCL)" if gloo_gather else ""))
                                if world > 1 else "single GPU",
                 "kernel": shape,
                 "device": info,
@@ -459,7 +484,10 @@ def main():
             "runtime": runtime,
         }
         if sharded:
-            out["rccl_nranks"] = extras["rccl"]["nranks_reported"]["min"]
+            # ncclCommCount as seen by every rank's communicator -- null when a rank holds none (host transport, dry run)
+            out["rccl_nranks"] = (extras["rccl"]["nranks_reported"]["min"]
+                                  if extras["rccl"]["ranks_with_communicator"] == world else None)
+            out["transport"] = "host (gloo all-gather through page-locked staging)" if gloo_gather else "rccl (in-stream ncclAllGather)"
         out.update(extras)
         if cpu is not None:
             out["cpu_baseline"] = cpu

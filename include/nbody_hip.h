@@ -204,6 +204,20 @@ void nb_hip_comm_unique_id(void *out128);
  */
 SimPipeline *CreateSimPipelineSharded(WorldData data, int rank, int nranks, const void *unique_id128);
 
+/*
+ * The same sharded pipeline over a caller-supplied transport instead of RCCL (MPI, gloo, shared memory ...): an
+ * in-place all-gather over HOST memory.  buf holds nranks slots of bytes_per_rank bytes; on entry slot `rank` is
+ * filled, on return every slot must hold what the owning rank put there.  The callback runs on the caller's thread,
+ * inside PerformSimUpdate / GetSimulationData, once per step (source positions, Mc float2 per rank) and once per Get
+ * (particle slices); every rank must reach it the same number of times.  The pipeline stages through one page-locked
+ * buffer (D2H own slot, wait, callback, H2D all slots), so this route costs a host round trip per step: it exists for
+ * machines without RCCL and for exercising the multi-process path with several ranks on ONE GPU (RCCL refuses two
+ * ranks on a device).  Everything else -- shard plan, kernels, mirror / gather layout, overlap mode -- is the RCCL
+ * path's; "sharded_graph" is ignored (a host callback cannot run inside a captured graph).
+ */
+typedef void (*NbAllGatherFn)(void *ctx, void *buf, uint64_t bytes_per_rank, int rank, int nranks);
+SimPipeline *CreateSimPipelineShardedWith(WorldData data, int rank, int nranks, NbAllGatherFn allgather, void *ctx);
+
 /* The shard arithmetic, pure host code (usable without a GPU). */
 typedef struct NbShardPlan {
     uint32_t mass_chunk;   /* Mc: massive slots per rank = all-gather count (uniform)   */

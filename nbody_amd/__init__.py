@@ -34,6 +34,9 @@ class NbShardPlan(C.Structure):
                                           "zero_begin", "zero_count", "src_padded")]
 
 
+# include/nbody_hip.h NbAllGatherFn: (ctx, buf, bytes_per_rank, rank, nranks)
+ALLGATHER_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int)
+
 # every symbol include/nbody_hip.h declares: (restype, argtypes)
 HIP_API = {
     "CreateSimPipeline": (C.c_void_p, [WorldData]),
@@ -61,6 +64,7 @@ HIP_API = {
                                   C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "nb_hip_comm_unique_id": (None, [C.c_void_p]),
     "CreateSimPipelineSharded": (C.c_void_p, [WorldData, C.c_int, C.c_int, C.c_void_p]),
+    "CreateSimPipelineShardedWith": (C.c_void_p, [WorldData, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]),
     "nb_hip_shard_plan": (NbShardPlan, [C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
     "nb_hip_local_group_create": (C.c_int, [WorldData, C.c_int, C.POINTER(C.c_void_p)]),
     "nb_hip_local_group_step": (None, [C.POINTER(C.c_void_p), C.c_int, C.c_uint32, C.c_float]),
@@ -164,10 +168,19 @@ class SimPipeline:
     `mass_len` massive ones, exactly what reference src/lib/world.c:32-58 hands its backend.
     """
 
-    def __init__(self, total_len, mass_len, rank=0, nranks=1, unique_id=None):
+    def __init__(self, total_len, mass_len, rank=0, nranks=1, unique_id=None, allgather=None):
+        """allgather: a Python callable (buf: writable uint8 array of shape (nranks, bytes_per_rank), rank, nranks) that
+        fills every row with its owner's bytes -- the caller-supplied host transport (CreateSimPipelineShardedWith)."""
         L = hip_lib()
         wd = WorldData(total_len, mass_len, 0.0)
-        if nranks > 1 or unique_id is not None:
+        self._cb = None
+        if allgather is not None:
+            def thunk(_ctx, buf, bytes_per_rank, r, n):
+                rows = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(n, int(bytes_per_rank)))
+                allgather(rows, r, n)
+            self._cb = ALLGATHER_FN(thunk)   # must outlive the pipeline
+            self._h = L.CreateSimPipelineShardedWith(wd, rank, nranks, self._cb, None)
+        elif nranks > 1 or unique_id is not None:
             idbuf = (C.c_ubyte * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
             self._h = L.CreateSimPipelineSharded(wd, rank, nranks, idbuf)
         else:

@@ -283,6 +283,12 @@ struct SimPipeline {
     NbShardPlan plan;
     ncclComm_t comm = nullptr;
     struct LocalGroup *group = nullptr;  // test transport: all ranks are pipelines of this process (no RCCL)
+    // caller-supplied transport (CreateSimPipelineShardedWith): an in-place all-gather over HOST memory; the pipeline
+    // stages each exchange through one page-locked buffer (D2H own slot, wait, callback, H2D all slots)
+    NbAllGatherFn host_gather = nullptr;
+    void *host_gather_ctx = nullptr;
+    void *stage = nullptr;        // page-locked staging, max(gathered sources, gathered particle slices) bytes
+    size_t stage_bytes = 0;
 
     bool on_device = false;  // buffers exist and hold data
     uint32_t slots = 0;      // receiver slots on this device (allocation; includes a shard's pad slots)
@@ -422,6 +428,9 @@ void release_device(SimPipeline *s) {
     dev_free(s->src_gm);
     dev_free(s->aos);
     dev_free(s->aos_shard);
+    if (s->stage) ASSERT_HIP(hipHostFree(s->stage), "hipHostFree staging");
+    s->stage = nullptr;
+    s->stage_bytes = 0;
     dev_free(s->parts);
     s->parts = nullptr;
     s->parts_cap = 0;
@@ -473,6 +482,12 @@ void materialize(SimPipeline *s) {
     } else {
         for (int b = 0; b < 2; b++) s->src_pos[b] = dev_alloc<float2>(s->n_src);
         s->aos_shard = dev_alloc<Particle>((size_t)s->slots * (size_t)s->nranks);
+        if (s->host_gather) {
+            const size_t a = (size_t)s->n_src * sizeof(float2), b = (size_t)s->slots * (size_t)s->nranks * sizeof(Particle);
+            s->stage_bytes = a > b ? a : b;
+            ASSERT_HIP(hipHostMalloc(&s->stage, s->stage_bytes ? s->stage_bytes : 1, hipHostMallocDefault), "staging of %zu bytes",
+                       s->stage_bytes);
+        }
     }
     s->on_device = true;
     pin_host(s);
@@ -704,6 +719,21 @@ void enqueue_single(SimPipeline *s, uint32_t n, float dt) {
 
 // ---- sharded chains --------------------------------------------------------------------------------------------
 
+// In-place all-gather of a device array of nranks slots through the caller's host transport: own slot down, wait,
+// callback (blocks until every rank's slot is in the staging buffer), everything up.  The stream stays ordered: what
+// was enqueued before has completed when the callback runs, what is enqueued after sees the gathered array.
+void host_allgather(SimPipeline *s, void *dev_base, size_t bytes_per_rank, hipStream_t st) {
+    NB_ASSERT(bytes_per_rank * (size_t)s->nranks <= s->stage_bytes, "staging too small: %zu x %d > %zu", bytes_per_rank, s->nranks,
+              s->stage_bytes);
+    char *host = static_cast<char *>(s->stage);
+    char *dev = static_cast<char *>(dev_base);
+    const size_t mine = (size_t)s->rank * bytes_per_rank;
+    ASSERT_HIP(hipMemcpyAsync(host + mine, dev + mine, bytes_per_rank, hipMemcpyDeviceToHost, st), "D2H of the own slot");
+    ASSERT_HIP(hipStreamSynchronize(st), "sync before the host all-gather");
+    s->host_gather(s->host_gather_ctx, host, (uint64_t)bytes_per_rank, s->rank, s->nranks);
+    ASSERT_HIP(hipMemcpyAsync(dev, host, bytes_per_rank * (size_t)s->nranks, hipMemcpyHostToDevice, st), "H2D of the gathered slots");
+}
+
 void allgather_sources(SimPipeline *s, int buf, hipStream_t st) {
     // in place: this rank's slice already sits at rank * Mc (written by the step kernel's mirror store)
     const size_t per_rank = (size_t)s->plan.mass_chunk * 2;  // floats
@@ -718,6 +748,10 @@ void allgather_sources(SimPipeline *s, int buf, hipStream_t st) {
                                       per_rank * sizeof(float), hipMemcpyDeviceToDevice, st),
                        "local push of rank %d's sources", s->rank);
         }
+        return;
+    }
+    if (s->host_gather) {
+        host_allgather(s, base, per_rank * sizeof(float), st);
         return;
     }
     ASSERT_NCCL(rccl().AllGather(base + (size_t)s->rank * per_rank, base, per_rank, NCCL_FLOAT32, s->comm, st),
@@ -816,7 +850,7 @@ StepGraph *capture_sharded_chain(SimPipeline *s, uint32_t n, float dt, nb::Launc
 void enqueue_sharded(SimPipeline *s, uint32_t n, float dt) {
     NB_ASSERT(s->group == nullptr, "members of a local group step through nb_hip_local_group_step");
     const nb::LaunchShape sh = resolve_shape(s);
-    if (s->sharded_graph && !s->overlap && n > 1) {
+    if (s->sharded_graph && !s->overlap && n > 1 && !s->host_gather) {  // a host callback cannot run inside a captured graph
         uint32_t left = n;
         while (left > 0) {
             const uint32_t chunk = left > GRAPH_CHAIN_MAX ? GRAPH_CHAIN_MAX : left;
@@ -1037,6 +1071,21 @@ SimPipeline *CreateSimPipelineSharded(WorldData data, int rank, int nranks, cons
     return s;
 }
 
+SimPipeline *CreateSimPipelineShardedWith(WorldData data, int rank, int nranks, NbAllGatherFn allgather, void *ctx) {
+    NB_ASSERT(nranks >= 1 && rank >= 0 && rank < nranks, "rank %d of %d", rank, nranks);
+    NB_ASSERT(allgather != nullptr, "NULL all-gather callback");
+    SimPipeline *s = CreateSimPipeline(data);
+    s->rank = rank;
+    s->nranks = nranks;
+    s->sharded = true;
+    s->plan = nb_hip_shard_plan(data.total_len, data.mass_len, rank, nranks);
+    s->host_gather = allgather;
+    s->host_gather_ctx = ctx;
+    const char *ov = getenv("NB_HIP_OVERLAP");
+    if (ov) s->overlap = atoi(ov) ? 1 : 0;
+    return s;
+}
+
 void nb_hip_plan_launch(uint32_t n_recv, uint32_t n_src, int compute_units, int *k, int *w, int *split, uint32_t *workgroups) {
     const nb::LaunchShape sh = nb::choose_shape({0, 0, nb::VARIANT_SMEM, 0}, n_recv, n_src, compute_units);
     if (k) *k = sh.k;
@@ -1167,8 +1216,11 @@ void GetSimulationData(const SimPipeline *cs, Particle *ps) {
         } else {
             nb::launch_merge(st, mine, 0, s->slots, s->pos[s->cur], s->vel, s->acc, s->radius, s->mass, 0);
             const size_t floats = (size_t)s->slots * (sizeof(Particle) / sizeof(float));
-            ASSERT_NCCL(rccl().AllGather(mine, shard, floats, NCCL_FLOAT32, s->comm, st),
-                        "ncclAllGather of particle slices");
+            if (s->host_gather)
+                host_allgather(s, shard, floats * sizeof(float), st);
+            else
+                ASSERT_NCCL(rccl().AllGather(mine, shard, floats, NCCL_FLOAT32, s->comm, st),
+                            "ncclAllGather of particle slices");
         }
         for (int q = 0; q < s->nranks; q++) {
             const NbShardPlan pq = nb_hip_shard_plan(N, s->data.mass_len, q, s->nranks);
@@ -1262,8 +1314,8 @@ int nb_hip_comm_info(const SimPipeline *s, int *nranks, int *rank, int *device, 
     if (device) *device = g_dev.ordinal;
     if (rccl_version) *rccl_version = 0;
     if (first_gather_ms) *first_gather_ms = s->first_gather_ms;
-    if (lib_path && len) lib_path[0] = 0;
-    if (s->comm == nullptr) return 0;  // unsharded, or a local-group member: no communicator
+    if (lib_path && len) snprintf(lib_path, len, "%s", s->host_gather ? "caller-supplied host all-gather" : s->group ? "local group" : "");
+    if (s->comm == nullptr) return 0;  // unsharded, a local-group member or a caller-supplied transport: no communicator
     // everything below is what the COMMUNICATOR says, not what the caller passed at creation
     if (nranks) ASSERT_NCCL(rccl().CommCount(s->comm, nranks), "ncclCommCount");
     if (rank) ASSERT_NCCL(rccl().CommUserRank(s->comm, rank), "ncclCommUserRank");

@@ -17,6 +17,7 @@ def declared_functions(header):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)          # comments
     text = re.sub(r"static inline[^{]*\{[^}]*\}", "", text)     # inline helpers are not exports
+    text = re.sub(r"typedef[^;{]*\(\s*\*\s*\w+\s*\)\s*\([^;]*\);", "", text)   # function-pointer typedefs are not exports
     names = [m.group(1) for m in FUNC.finditer(text)]
     return [n for n in names if n not in ("defined", "static_assert", "_Static_assert")]
 

@@ -920,3 +920,95 @@ def test_reference_bench_c_runs_unchanged_on_our_library():
     rows = [l.split() for l in r.stdout.strip().splitlines()]
     assert rows[0] == ["N", "GPU"]
     assert [int(x[0]) for x in rows[1:]] == [250, 500, 800, 1200, 2000, 4000, 10000, 20000, 50000, 100000]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# several REAL processes through pipeline.hip's sharded host code on this one GPU (caller-supplied host transport)
+# ---------------------------------------------------------------------------------------------------------------
+
+_MULTI_PROC_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+root = sys.argv[1]; out_path = sys.argv[2]; n = int(sys.argv[3]); overlap = int(sys.argv[4])
+sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, root)
+import nbody_amd as nb, oracle_binding as ob
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+ic = np.fromfile(os.path.join(root, "tests", "golden", f"ic_{n}.bin"), dtype=np.float32).reshape(-1, 8)
+part, m = ob.partition(ic)
+calls = []
+def gather(rows, r, nr):
+    calls.append(rows.shape)
+    mine = torch.from_numpy(rows[r].copy())
+    parts = [torch.empty_like(mine) for _ in range(nr)]
+    dist.all_gather(parts, mine)
+    for q in range(nr):
+        if q != r: rows[q] = parts[q].numpy()
+res = {}
+for tag, knobs in (("w1", dict(w=1, k=1)), ("auto", dict())):
+    sim = nb.SimPipeline(n, m, rank=rank, nranks=world, allgather=gather)
+    sim.configure(overlap=overlap, **knobs)
+    sim.set_data(part)
+    sim.update(2, 0.01); sim.update(1, 0.01)
+    steps, k_ms, c_ms = sim.step_breakdown()
+    assert steps == 1 and k_ms > 0 and c_ms > 0
+    info = sim.comm_info()
+    assert not info["owns_comm"] and info["nranks"] == world and info["rank"] == rank and "host" in info["rccl_lib"]
+    res[tag] = sim.get_data()          # collective: every rank gets the full array
+    sim.close()
+plan = nb.shard_plan(n, m, rank, world)
+assert len(calls) == 2 * (3 + 1) and calls[0] == (world, plan["mass_chunk"] * 8)
+# every rank must hold the same bytes
+for tag in res:
+    mine = torch.from_numpy(res[tag].view(np.uint8).reshape(-1).copy())
+    ref = mine.clone(); dist.broadcast(ref, src=0)
+    assert bool((mine == ref).all()), f"rank {rank} differs from rank 0 ({tag})"
+if rank == world - 1:                  # written by the LAST rank: a rank > 0 produced the checked bytes
+    np.save(out_path, np.stack([res["w1"], res["auto"]]))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,n,overlap", [(2, 1024, 0), (3, 333, 1), (4, 4096, 1)])
+def test_sharded_pipeline_with_real_processes_on_one_gpu(golden, tmp_path, world, n, overlap):
+    """pipeline.hip's sharded host code with `world` REAL processes (ranks > 0 in their own address space, collective
+    Get included), all on this one GPU: the exchange goes through the caller-supplied host transport
+    (CreateSimPipelineShardedWith) over gloo, because RCCL refuses two ranks on one device.  Everything but the
+    ncclAllGather call itself is the RCCL path's code.  W = 1: bit-equal to the single pipeline; auto shape: within
+    the one-step tolerance chain (three steps, positions <= 1e-6 relative L2 of the single pipeline)."""
+    worker = tmp_path / "worker.py"
+    worker.write_text(_MULTI_PROC_WORKER)
+    out = tmp_path / "out.npy"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29800 + world), str(worker), nb.ROOT, str(out), str(n), str(overlap)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    got = np.load(out)
+    part, m = ob.partition(golden(f"ic_{n}.bin"))
+    assert got[0].tobytes() == run(part, m, 3, 0.01, w=1, k=1).tobytes()
+    want = run(part, m, 3, 0.01)
+    assert rel_l2_pos(got[1], want) <= 1e-6
+    assert np.array_equal(got[1][:, 6:8], want[:, 6:8])
+
+
+def test_bench_with_two_real_ranks_on_one_gpu():
+    """bench.py as the driver launches it for N = 2 -- two processes, barriers, reductions over the ranks, self-check
+    against the single-GPU pipeline, extra_configs -- with both ranks on this one GPU over the host transport."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29741", os.path.join(nb.ROOT, "bench.py"), "--gpus", "2", "--transport", "host",
+           "--steps", "4", "--warmup", "1", "--particles", "65536", "--extra-particles", "131072"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=nb.ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]      # stdout carries the JSON line only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 1e10 and out["rccl_nranks"] is None and out["transport"].startswith("host")
+    assert out["rccl"]["user_ranks"] == {"min": 0, "max": 1, "sum": 1} and out["rccl"]["ranks_with_communicator"] == 0
+    check = out["self_check"]
+    assert check["ranks_agree"] is True and check["static_fields_equal"] is True and check["steps"] == 5
+    assert check["vs_single_gpu_rel_l2_pos"] <= 1e-6
+    assert out["kernel_ms_per_step"]["min"] > 0 and out["comm_ms_per_step"]["max"] > 0
+    assert [e["overlap"] for e in out["extra_configs"]] == [1, 0, 1]
+    assert all(e["value"] > 1e10 and e["kernel_ms_per_step"]["max"] > 0 for e in out["extra_configs"])
