@@ -125,9 +125,10 @@ uint32_t nb_hip_last_step_breakdown(SimPipeline *sim, double *kernel_ms, double 
 int nb_hip_comm_info(const SimPipeline *sim, int *nranks, int *rank, int *device, int *rccl_version,
                      double *first_gather_ms, char *lib_path, uint32_t len);
 
-/* Cached hipGraph chains of this pipeline (at most 8, least recently used evicted); *patches = times a cached
- * chain's kernel-node parameters were rewritten because dt changed. */
-uint32_t nb_hip_graph_stats(const SimPipeline *sim, uint32_t *patches);
+/* Cached hipGraph chains of this pipeline (at most 8, least recently used evicted); *dt_uploads = times a new step
+ * size was written to device memory (the kernels read dt from there, like the reference's uniform block,
+ * sim_gpu.c:268-284, so a changed dt never rebuilds or patches a cached chain). */
+uint32_t nb_hip_graph_stats(const SimPipeline *sim, uint32_t *dt_uploads);
 
 /* hipRuntimeGetVersion() of the HIP runtime this process actually bound (0 when it cannot be asked). */
 int nb_hip_runtime_version(void);
@@ -152,11 +153,14 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
  *   "passes"    launches per step over consecutive source sub-ranges, chained through acc[]: 0 = auto (each
  *               pass's sources fit one XCD's L2, so they are fetched once per pass instead of once per round:
  *               23x less memory-side traffic at N = 2^20, same speed), else 1..64
- *   "graph"     how PerformSimUpdate(n > 1) runs its chain: 1 = always as a hipGraph (built on first use, cached,
- *               per (length, ping-pong phase), patched when dt changes), 0 = plain stream launches, 2 (default) = a chain length runs as plain
- *               launches the first time it is asked for and as a hipGraph from the second time on (building a
- *               chain costs more than one replay saves), and chains shorter than 16 steps always do (a graph launch
- *               costs the host ~12 us more than a few plain launches)
+ *   "graph"     how PerformSimUpdate(n > 1) runs its chain: 0 = plain stream launches; 1 = always as a hipGraph, built on
+ *               first use and cached per (length, ping-pong phase); 2 (default) = auto: calls shorter than 16 steps are
+ *               plain launches (a graph launch costs the host ~12 us more than a few plain launches).  Longer calls on
+ *               small worlds (N x M <= 2.1e8: a step of <= ~40 us, where a replayed node is 0.7-1.9 us cheaper than a
+ *               plain launch) replay ONE canonical 32-step chain that is built when the data first reaches the device,
+ *               with plain launches for the remainder; on larger worlds a chain length runs as plain launches the first
+ *               time it is asked for and as a cached hipGraph from the second time on (a replay saves nothing there).
+ *               The step size is never baked into a chain: kernels read it from device memory.
  *   "readback"  when the device state reaches the host array named by nb_hip_note_host_array: 0 = only when
  *               GetSimulationData asks (merge kernel + D2H copy + wait), 1 = at the end of every blocking
  *               PerformSimUpdate (the merge kernel is appended to the update's own submission and stores straight into

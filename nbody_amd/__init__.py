@@ -243,9 +243,10 @@ class SimPipeline:
                 "first_gather_ms": ms.value, "rccl_lib": path.value.decode()}
 
     def graph_stats(self):
-        patches = C.c_uint32(0)
-        cached = hip_lib().nb_hip_graph_stats(self._h, C.byref(patches))
-        return {"cached": int(cached), "patches": int(patches.value)}
+        """cached hipGraph chains and how often a new step size was written to device memory."""
+        uploads = C.c_uint32(0)
+        cached = hip_lib().nb_hip_graph_stats(self._h, C.byref(uploads))
+        return {"cached": int(cached), "dt_uploads": int(uploads.value)}
 
     def configure(self, **knobs):
         for k, v in knobs.items():

@@ -41,7 +41,9 @@ struct StepParams {
     // the next gathered source array); n_mirror == 0 disables it
     float2 *mirror;
     uint32_t n_mirror;
-    float dt;
+    // step size, read from device memory -- where the reference keeps it too (the uniform block, sim_gpu.h:8-12,
+    // re-uploaded when dt changes, sim_gpu.c:268-284).  A hipGraph chain therefore never needs re-patching for a new dt.
+    const float *dt;
     uint32_t flags;
     // source split: gridDim.y = split workgroups share one receiver tile, each over 1/split of the source
     // chunks; with split > 1 the step kernel only stores its sums to parts[part][receiver] and finish_kernel
@@ -84,6 +86,8 @@ void launch_make_gm(hipStream_t st, const float *mass, float *gm, uint32_t count
 // merge: soa slots [slot0 .. slot0+count) -> aos[first .. first+count)
 void launch_merge(hipStream_t st, void *aos, uint32_t first, uint32_t count, const float2 *pos, const float2 *vel,
                   const float2 *acc, const float *radius, const float *mass, uint32_t slot0);
+// *dst = value, in stream order (the step-size upload)
+void launch_set_scalar(hipStream_t st, float *dst, float value);
 // sharded upload: both gathered source arrays + G*m from the AoS world; slots in [mass_len, n_src) become inert pads
 void launch_split_sources(hipStream_t st, const void *aos, uint32_t mass_len, uint32_t n_src, float2 *pos0, float2 *pos1,
                           float *gm);

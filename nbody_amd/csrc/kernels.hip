@@ -170,7 +170,9 @@ __device__ __forceinline__ uint32_t source_index(const StepParams &p, uint32_t v
 }
 
 // Epilogue of one receiver: optional carried-in sum, store acc, then the reference's integrator.
-__device__ __forceinline__ void finish_receiver(const StepParams &p, uint32_t logical, float sx, float sy) {
+// `early` = the receiver's vel / pos_in were already fetched at kernel start (v0, q0); otherwise they are loaded here.
+__device__ __forceinline__ void finish_receiver(const StepParams &p, uint32_t logical, float sx, float sy, float dt,
+                                                bool early = false, float2 v0 = float2{0.f, 0.f}, float2 q0 = float2{0.f, 0.f}) {
     if (logical >= p.n_recv) return;
     const uint32_t i = receiver_slot(p, logical);
     float2 a = make_float2(sx, sy);
@@ -182,12 +184,12 @@ __device__ __forceinline__ void finish_receiver(const StepParams &p, uint32_t lo
     p.acc[i] = a;
     if (p.flags & STEP_NO_FINALIZE) return;
     // semi-implicit Euler with the reference's roundings: vel += acc*dt; pos += vel*dt
-    float2 v = p.vel[i];
-    v.x = __fadd_rn(v.x, __fmul_rn(a.x, p.dt));
-    v.y = __fadd_rn(v.y, __fmul_rn(a.y, p.dt));
-    float2 q = p.pos_in[i];
-    q.x = __fadd_rn(q.x, __fmul_rn(v.x, p.dt));
-    q.y = __fadd_rn(q.y, __fmul_rn(v.y, p.dt));
+    float2 v = early ? v0 : p.vel[i];
+    v.x = __fadd_rn(v.x, __fmul_rn(a.x, dt));
+    v.y = __fadd_rn(v.y, __fmul_rn(a.y, dt));
+    float2 q = early ? q0 : p.pos_in[i];
+    q.x = __fadd_rn(q.x, __fmul_rn(v.x, dt));
+    q.y = __fadd_rn(q.y, __fmul_rn(v.y, dt));
     p.vel[i] = v;
     p.pos_out[i] = q;
     if (i < p.n_mirror) p.mirror[i] = q;
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
     const float2 a0 = p.acc[i];
     const float2 v0 = p.vel[i];
     const float2 q0 = p.pos_in[i];
+    const float dt = *p.dt;
     float sx = 0.0f, sy = 0.0f;
 #pragma unroll
     for (uint32_t s = 0; s < (uint32_t)MAX_SPLIT; s++) {
@@ -230,10 +233,10 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
     if (!integrate) return;
     // semi-implicit Euler with the reference's roundings (finish_receiver): vel += acc*dt; pos += vel*dt
     float2 v = v0, q = q0;
-    v.x = __fadd_rn(v.x, __fmul_rn(a.x, p.dt));
-    v.y = __fadd_rn(v.y, __fmul_rn(a.y, p.dt));
-    q.x = __fadd_rn(q.x, __fmul_rn(v.x, p.dt));
-    q.y = __fadd_rn(q.y, __fmul_rn(v.y, p.dt));
+    v.x = __fadd_rn(v.x, __fmul_rn(a.x, dt));
+    v.y = __fadd_rn(v.y, __fmul_rn(a.y, dt));
+    q.x = __fadd_rn(q.x, __fmul_rn(v.x, dt));
+    q.y = __fadd_rn(q.y, __fmul_rn(v.y, dt));
     p.vel[i] = v;
     p.pos_out[i] = q;
     if (i < p.n_mirror) p.mirror[i] = q;
@@ -254,6 +257,28 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
     // per wave, double-buffered: 64 interleaved (x, y) pairs, then 64 G*m
     __shared__ __attribute__((aligned(16))) float tile[VARIANT == VARIANT_LDS ? W : 1][2][3 * CHUNK];
     __shared__ float2 partial[W > 1 ? W : 1][W > 1 ? WAVE * K : 1];
+
+    // Latency-bound launches (a few thousand particles: the whole step is a handful of dependent memory round trips)
+    // fetch what the epilogue needs -- the step size and the velocity / position of the receiver this THREAD will
+    // integrate -- together with the receivers, instead of after the force loop: one round trip less on the critical
+    // path.  Only when this launch integrates (unsplit, finalising); big launches are issue-bound and skip it.
+    // (not for tuning shapes with several receivers per finishing thread, and not on the LDS route, whose staging
+    // registers leave no room: it would spill)
+    constexpr bool EARLY_FETCH = (W == 1 || W >= K) && VARIANT == VARIANT_SMEM;
+    const bool integrates_here = EARLY_FETCH && p.split == 1 && (p.flags & STEP_NO_FINALIZE) == 0;
+    const float dt = *p.dt;
+    float2 early_v[W == 1 ? K : 1], early_q[W == 1 ? K : 1];
+#pragma unroll
+    for (int k = 0; k < (W == 1 ? K : 1); k++) {
+        early_v[k] = early_q[k] = float2{0.f, 0.f};
+        // W == 1: lane finishes its own K receivers; W > 1: thread tid finishes receiver recv_base + tid (tid < 64 K)
+        const uint32_t logical = W == 1 ? recv_base + k * WAVE + lane : recv_base + tid;
+        if (integrates_here && (W == 1 || tid < WAVE * K) && logical < p.n_recv) {
+            const uint32_t i = receiver_slot(p, logical);
+            early_v[k] = p.vel[i];
+            early_q[k] = p.pos_in[i];
+        }
+    }
 
     Receivers<K> R;
 #pragma unroll
@@ -380,17 +405,17 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
     }
 
     // ---- combine the W slices in wave order, integrate, store -------------------------------------------
-    auto finish = [&](uint32_t logical, float sx, float sy) {
+    auto finish = [&](uint32_t logical, float sx, float sy, int k) {
         if (p.split > 1) {
             if (logical < p.n_recv) p.parts[(size_t)blockIdx.y * p.n_recv + logical] = make_float2(sx, sy);
         } else {
-            finish_receiver(p, logical, sx, sy);
+            finish_receiver(p, logical, sx, sy, dt, integrates_here, early_v[k], early_q[k]);
         }
     };
 
     if constexpr (W == 1) {
 #pragma unroll
-        for (int k = 0; k < K; k++) finish(recv_base + k * WAVE + lane, R.s[k].x, R.s[k].y);
+        for (int k = 0; k < K; k++) finish(recv_base + k * WAVE + lane, R.s[k].x, R.s[k].y, k);
     } else {
 #pragma unroll
         for (int k = 0; k < K; k++) partial[wid][k * WAVE + lane] = make_float2(R.s[k].x, R.s[k].y);
@@ -404,7 +429,8 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
                 sx = __fadd_rn(sx, t.x);
                 sy = __fadd_rn(sy, t.y);
             }
-            finish(recv_base + slot, sx, sy);
+            // one receiver per thread (slot == tid) whenever the early fetch is on
+            finish(recv_base + slot, sx, sy, 0);
         }
     }
 }
@@ -449,6 +475,8 @@ __global__ void fill_pad_kernel(float2 *pos, float2 *vel, float2 *acc, float *ra
     radius[slot0 + i] = 1.0f;
     mass[slot0 + i] = 0.0f;
 }
+
+__global__ void set_scalar_kernel(float *dst, float value) { *dst = value; }
 
 __global__ void make_gm_kernel(const float *mass, float *gm, uint32_t count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -607,6 +635,10 @@ void launch_fill_pad(hipStream_t st, float2 *pos, float2 *vel, float2 *acc, floa
                      uint32_t count) {
     if (count == 0) return;
     hipLaunchKernelGGL(fill_pad_kernel, grid1d(count), dim3(256), 0, st, pos, vel, acc, radius, mass, slot0, count);
+}
+
+void launch_set_scalar(hipStream_t st, float *dst, float value) {
+    hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, st, dst, value);
 }
 
 void launch_make_gm(hipStream_t st, const float *mass, float *gm, uint32_t count) {

@@ -243,7 +243,6 @@ struct StepGraph {
     std::vector<hipGraphNode_t> nodes;  // one kernel node per launch, in order
     std::vector<nb::StepParams> params; // what each node currently holds
     int phase = -1;                     // which pos buffer the chain reads first
-    float dt = 0.0f;
     nb::LaunchShape shape = {0, 0, 0, 0};
     uint64_t last_use = 0;              // for eviction: the cache holds at most GRAPH_CACHE_MAX chains
 };
@@ -303,6 +302,13 @@ struct SimPipeline {
     float *mass = nullptr;
     float2 *src_pos[2] = {nullptr, nullptr};  // sharded only: gathered source positions (ping-pong)
     float *src_gm = nullptr;
+    // the step size lives in device memory, like the reference's uniform block (sim_gpu.h:8-12): kernels read it
+    // through StepParams::dt, a new value is written in stream order when PerformSimUpdate's dt differs from the last
+    // one enqueued (the reference's re-upload, sim_gpu.c:268-284), and no cached hipGraph ever needs re-patching
+    float *dt_dev = nullptr;
+    float dt_enqueued = 0.0f;
+    bool dt_valid = false;
+    uint32_t dt_uploads = 0;
     void *aos = nullptr;     // device AoS staging for Set/Get (whole world)
     void *aos_shard = nullptr;  // sharded only: this rank's slice, uniform size
     void *host_array = nullptr;  // caller's long-lived particle array (nb_hip_note_host_array), page-locked lazily
@@ -343,7 +349,6 @@ struct SimPipeline {
     std::vector<uint32_t> seen_chains;                  // chain lengths already run once as plain launches
     int want_passes = 0;  // source passes per step (0 = auto: keep each pass's sources within one XCD's L2)
     double first_gather_ms = 0.0;  // sharded: device time of the probe all-gather at creation (includes lazy setup)
-    uint32_t graph_patches = 0;  // times a cached chain's nodes were rewritten (dt changed); tooling reads it
     nb::LaunchShape last_shape = {0, 0, 0, 0};
     uint32_t last_groups = 0;
 
@@ -426,6 +431,9 @@ void release_device(SimPipeline *s) {
     dev_free(s->radius);
     dev_free(s->mass);
     dev_free(s->src_gm);
+    dev_free(s->dt_dev);
+    s->dt_dev = nullptr;
+    s->dt_valid = false;
     dev_free(s->aos);
     dev_free(s->aos_shard);
     if (s->stage) ASSERT_HIP(hipHostFree(s->stage), "hipHostFree staging");
@@ -474,6 +482,7 @@ void materialize(SimPipeline *s) {
     s->radius = dev_alloc<float>(cap);
     s->mass = dev_alloc<float>(cap);
     s->src_gm = dev_alloc<float>(s->n_src);
+    s->dt_dev = dev_alloc<float>(1);
     s->aos = dev_alloc<Particle>(N);
     if (!s->sharded) {
         // the first mass_len receivers ARE the sources: no separate source array
@@ -544,7 +553,8 @@ nb::StepParams whole_step(const SimPipeline *s, int in, float dt) {
         p.mirror = s->src_pos[in ^ 1] + (size_t)s->rank * s->plan.mass_chunk;
         p.n_mirror = s->plan.mass_count;
     }
-    p.dt = dt;
+    (void)dt;  // the value travels through device memory (upload_dt), the parameter block only points at it
+    p.dt = s->dt_dev;
     p.flags = 0;
     p.parts = nullptr;
     p.split = 1;
@@ -603,6 +613,15 @@ void launch_step(SimPipeline *s, nb::LaunchShape sh, const nb::StepParams &p, hi
     }
 }
 
+// The step size of everything enqueued from here on.  Written in stream order, so steps already queued keep theirs.
+void upload_dt(SimPipeline *s, float dt) {
+    if (s->dt_valid && memcmp(&dt, &s->dt_enqueued, sizeof dt) == 0) return;
+    nb::launch_set_scalar(s->stream, s->dt_dev, dt);
+    s->dt_enqueued = dt;
+    s->dt_valid = true;
+    s->dt_uploads++;
+}
+
 // ---- single-device chains ------------------------------------------------------------------------------------
 
 void fill_node(hipKernelNodeParams &kp, void **args, const void *fn, dim3 grid, dim3 block) {
@@ -618,8 +637,7 @@ void fill_node(hipKernelNodeParams &kp, void **args, const void *fn, dim3 grid, 
 // A cached chain is keyed on (length, passes, shape, PHASE): an odd chain length flips the ping-pong phase, so a
 // frame loop that asks for the same odd n alternates between two phases -- with the phase in the key it gets two
 // instantiated graphs and replays them untouched, instead of re-patching every node of one graph on every call.
-// dt is not part of the key: a changed dt patches the node parameters in place (the analogue of the reference
-// re-uploading its uniform, sim_gpu.c:268-284).
+// dt is not part of the key and never forces a rebuild or a patch: the nodes read it from device memory (upload_dt).
 StepGraph *find_graph(SimPipeline *s, uint32_t n, uint32_t passes, nb::LaunchShape sh, int phase) {
     for (auto &c : s->graphs)
         if (c.n == n && c.passes == passes && c.phase == phase && c.shape.k == sh.k && c.shape.w == sh.w &&
@@ -646,10 +664,7 @@ StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchS
         g->params.resize((size_t)n * passes);
     }
     g->last_use = ++s->use_clock;
-    if (!fresh && g->dt == dt) return g;
-    s->graph_patches += fresh ? 0 : 1;
-    // (re)write every node: at creation, or -- the analogue of the reference re-uploading its uniform when dt
-    // changes (sim_gpu.c:268-284) -- patch the instantiated graph when dt moved
+    if (!fresh) return g;
     hipGraphNode_t prev = nullptr;
     for (uint32_t i = 0; i < n; i++) {
         const std::vector<nb::StepParams> launches = step_passes(s, whole_step(s, (s->cur + i) & 1, dt), sh);
@@ -663,20 +678,31 @@ StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchS
                 else
                     fill_node(kp, args, nb::finish_kernel_fn(), nb::finish_grid(s->n_real), nb::finish_block());
                 hipGraphNode_t &node = g->nodes[(size_t)i * per_step + q * per_pass + j];
-                if (fresh) {
-                    ASSERT_HIP(hipGraphAddKernelNode(&node, g->graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp),
-                               "hipGraphAddKernelNode step %u/%u", i, n);
-                    prev = node;
-                } else {
-                    ASSERT_HIP(hipGraphExecKernelNodeSetParams(g->exec, node, &kp), "hipGraphExecKernelNodeSetParams");
-                }
+                ASSERT_HIP(hipGraphAddKernelNode(&node, g->graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp),
+                           "hipGraphAddKernelNode step %u/%u", i, n);
+                prev = node;
             }
         }
     }
-    if (fresh) ASSERT_HIP(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0), "hipGraphInstantiate (%u steps)", n);
+    ASSERT_HIP(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0), "hipGraphInstantiate (%u steps)", n);
     g->phase = s->cur;
-    g->dt = dt;
     return g;
+}
+
+// graph = 2 (auto) on small worlds: ONE canonical chain of CANON_STEPS steps starting at phase 0, built when the data
+// first reaches the device (outside any step call) and replayed by every call of 16+ steps: a step or two of plain
+// launches to reach phase 0, whole replays (even length: the phase stays 0), the remainder as plain launches.  A
+// replayed node costs 0.7-1.9 us less than a plain launch below N ~ 10 000 (4.23 -> 4.08 us per step at N = 250,
+// 5.14 -> 4.49 at 1 000, 8.58 -> 6.69 at 4 000, 20.0 -> 18.7 at 10 000: profiles/r02_graph_chunk_probe.txt) and
+// nothing above ~20 000, where a launch's latency hides behind the previous kernel; building the 32-step chain costs
+// 95-150 us once.  So the reference's nbody-bench -- ONE 100-step call per world (bench.c:30-33) -- runs 96 of its 100
+// steps at the replay rate without ever paying for a build inside the call.
+constexpr uint32_t CANON_STEPS = 32;
+constexpr double CANON_MAX_PAIRS = 2.1e8;  // N x M up to which a step is short enough (~40 us) for a replay to pay
+
+bool wants_canonical(const SimPipeline *s) {
+    return !s->sharded && s->use_graph == 2 && s->n_real > 0 &&
+           (double)s->n_real * (double)(s->n_src ? s->n_src : 1) <= CANON_MAX_PAIRS;
 }
 
 void enqueue_single(SimPipeline *s, uint32_t n, float dt) {
@@ -689,6 +715,23 @@ void enqueue_single(SimPipeline *s, uint32_t n, float dt) {
         return;
     }
     uint32_t left = n;
+    if (wants_canonical(s)) {
+        if (s->cur == 1 && left > 0) {  // reach phase 0
+            launch_step(s, sh, whole_step(s, s->cur, dt), s->stream);
+            s->cur ^= 1;
+            left--;
+        }
+        while (left >= CANON_STEPS) {
+            StepGraph *g = find_or_build_graph(s, CANON_STEPS, dt, sh);  // prebuilt at SetSimulationData unless a knob moved
+            ASSERT_HIP(hipGraphLaunch(g->exec, s->stream), "hipGraphLaunch (canonical %u steps)", CANON_STEPS);
+            left -= CANON_STEPS;
+        }
+        for (; left > 0; left--) {
+            launch_step(s, sh, whole_step(s, s->cur, dt), s->stream);
+            s->cur ^= 1;
+        }
+        return;
+    }
     while (left > 0) {
         // full chains have even length so that replaying them keeps the ping-pong phase
         const uint32_t chunk = left > GRAPH_CHAIN_MAX ? GRAPH_CHAIN_MAX : left;
@@ -825,7 +868,7 @@ void sharded_step(SimPipeline *s, nb::LaunchShape sh, float dt, hipStream_t cs, 
 // stream capture is the least-travelled path of this library (exercised with one rank only, tests).
 StepGraph *capture_sharded_chain(SimPipeline *s, uint32_t n, float dt, nb::LaunchShape sh) {
     for (auto &c : s->graphs)
-        if (c.n == n && c.dt == dt && c.phase == s->cur && c.shape.k == sh.k && c.shape.w == sh.w &&
+        if (c.n == n && c.phase == s->cur && c.shape.k == sh.k && c.shape.w == sh.w &&
             c.shape.variant == sh.variant && c.shape.split == sh.split) {
             c.last_use = ++s->use_clock;
             return &c;
@@ -835,7 +878,6 @@ StepGraph *capture_sharded_chain(SimPipeline *s, uint32_t n, float dt, nb::Launc
     StepGraph *g = &s->graphs.back();
     g->last_use = ++s->use_clock;
     g->n = n;
-    g->dt = dt;
     g->phase = s->cur;
     g->shape = sh;
     const int cur0 = s->cur;
@@ -875,6 +917,7 @@ void enqueue_steps(SimPipeline *s, uint32_t n, float dt) {
     s->comm_iv.clear();
     s->detail_steps = 0;
     s->host_current = false;
+    upload_dt(s, dt);
     if (s->timing) ASSERT_HIP(hipEventRecord(s->ev_begin, s->stream), "record begin");
     if (!s->sharded)
         enqueue_single(s, n, dt);
@@ -1121,6 +1164,7 @@ void nb_hip_local_group_step(SimPipeline **sims, int nranks, uint32_t n, float d
     NB_ASSERT((int)g->members.size() == nranks, "group has %zu members, %d passed", g->members.size(), nranks);
     for (int r = 0; r < nranks; r++) NB_ASSERT(sims[r]->on_device, "member %d has no data", r);
     use_device();
+    for (int r = 0; r < nranks; r++) upload_dt(sims[r], dt);
     for (uint32_t i = 0; i < n; i++)
         for (int r = 0; r < nranks; r++) {
             SimPipeline *s = sims[r];
@@ -1179,6 +1223,8 @@ void SetSimulationData(SimPipeline *s, const Particle *ps) {
         if (s->overlap) ASSERT_HIP(hipEventRecord(s->ev_gather, s->group ? s->stream : s->comm_stream), "prime gather event");
     }
     ASSERT_HIP(hipStreamSynchronize(st), "sync after SetSimulationData");
+    // small worlds in auto mode: have the canonical chain ready before the first step call (see wants_canonical)
+    if (wants_canonical(s)) (void)find_or_build_graph(s, CANON_STEPS, 0.0f, resolve_shape(s));
 }
 
 void GetSimulationData(const SimPipeline *cs, Particle *ps) {
@@ -1327,7 +1373,7 @@ int nb_hip_comm_info(const SimPipeline *s, int *nranks, int *rank, int *device, 
 
 uint32_t nb_hip_graph_stats(const SimPipeline *s, uint32_t *patches) {
     NB_ASSERT(s != nullptr, "NULL pipeline");
-    if (patches) *patches = s->graph_patches;
+    if (patches) *patches = s->dt_uploads;
     return (uint32_t)s->graphs.size();
 }
 

@@ -249,10 +249,10 @@ def test_graph_chain_equals_plain_launches(golden, n_steps):
 
 @pytest.mark.parametrize("graph", [1, 2])
 def test_split_calls_and_odd_phases(golden, graph):
-    # graph = 2 (the default): chains of 16+ steps run as plain launches once, as a cached hipGraph from then on;
-    # shorter ones always as plain launches
+    # graph = 2 (the default) on a small world: one canonical 32-step chain, prebuilt at set_data, replayed by calls of
+    # 16+ steps (plain launches to reach phase 0 and for the remainder); shorter calls are plain launches
     part, m = ob.partition(golden("ic_333.bin"))
-    calls = (3, 3, 1, 5, 3, 3, 17, 17, 16, 17, 17)   # same chain lengths reused on the other ping-pong phase
+    calls = (3, 3, 1, 5, 3, 3, 17, 17, 16, 17, 17, 40, 33, 71, 32, 1, 64)   # lengths reused on the other ping-pong phase
     want = run(part, m, sum(calls), 0.01, graph=0)
     sim = nb.SimPipeline(333, m)
     sim.configure(graph=graph)
@@ -263,24 +263,23 @@ def test_split_calls_and_odd_phases(golden, graph):
     stats = sim.graph_stats()
     sim.close()
     assert got.tobytes() == want.tobytes()
-    # always: (3, both phases), (5, 1), (17, both phases), (16, 0); auto: only 17 on both phases -- 16 ran once, as
-    # plain launches, and the short chains never become graphs
-    assert stats["cached"] == (6 if graph == 1 else 2)
+    assert stats["cached"] == (8 if graph == 1 else 1)   # always: one per (length, phase), capped at 8; auto: the canonical one
+    assert stats["dt_uploads"] == 1
 
 
 @pytest.mark.parametrize("graph", [1, 2])
 def test_dt_change_patches_the_cached_chain(golden, graph):
     part, m = ob.partition(golden("ic_333.bin"))
-    n = 4 if graph == 1 else 16  # auto mode keeps chains shorter than 16 steps as plain launches
+    n = 4 if graph == 1 else 40  # auto mode: 40 = one replay of the canonical 32-step chain + 8 plain launches
     sim = nb.SimPipeline(333, m)
     sim.configure(graph=graph)
     sim.set_data(part)
     sim.update(n, 0.01)
-    sim.update(n, 0.005)         # same n, dt halved: kernel-node parameters are rewritten
+    sim.update(n, 0.005)         # same n, dt halved: a 4-byte write to device memory, the cached chain is untouched
     sim.update(n, 0.01)
     sim.update(n, 0.0025)
     got = sim.get_data()
-    assert sim.graph_stats()["patches"] == (3 if graph == 1 else 2)   # auto: the first call ran as plain launches
+    assert sim.graph_stats() == {"cached": 1, "dt_uploads": 4}
     sim.close()
     ref = nb.SimPipeline(333, m)
     ref.configure(graph=0)
@@ -572,20 +571,22 @@ def test_ten_steps_at_config2_size_against_the_avx_path():
 
 
 def test_config3_dt_halved_on_a_cached_chain():
-    """BASELINE config 3 literally: N = 262 144, a multi-step hipGraph chain, then the SAME cached chain at dt/2
-    (hipGraphExecKernelNodeSetParams rewrites dt in every node -- the analogue of sim_gpu.c:268-284) and back."""
+    """BASELINE config 3 literally: N = 262 144, a multi-step hipGraph chain, then the SAME cached chain at dt/2 and
+    back.  The step size lives in device memory like the reference's uniform block, so halving it is the reference's
+    own mechanism -- a small in-stream write when dt differs from the cached one (sim_gpu.c:268-284) -- and the
+    instantiated chain is replayed untouched."""
     n = 262144
     _, part, m = bench_universe(n)
     sim = nb.SimPipeline(n, m)
     sim.configure(graph=1)
     sim.set_data(part)
     sim.update(4, 0.01)
-    assert sim.graph_stats() == {"cached": 1, "patches": 0}
+    assert sim.graph_stats() == {"cached": 1, "dt_uploads": 1}
     sim.update(4, 0.005)            # cached chain, dt halved
-    assert sim.graph_stats() == {"cached": 1, "patches": 1}
-    sim.update(4, 0.005)            # replayed untouched
+    assert sim.graph_stats() == {"cached": 1, "dt_uploads": 2}
+    sim.update(4, 0.005)            # same dt: nothing written
     sim.update(4, 0.01)
-    assert sim.graph_stats() == {"cached": 1, "patches": 2}
+    assert sim.graph_stats() == {"cached": 1, "dt_uploads": 3}
     got = sim.get_data()
     sim.close()
     ref = nb.SimPipeline(n, m)
@@ -614,7 +615,7 @@ def test_odd_chain_lengths_get_one_cached_graph_per_phase(golden):
     sim.set_data(part)
     for _ in range(6):
         sim.update(3, 0.01)
-    assert sim.graph_stats() == {"cached": 2, "patches": 0}
+    assert sim.graph_stats() == {"cached": 2, "dt_uploads": 1}
     for n in range(1, 30):          # many chain lengths: least recently used chains are evicted
         sim.update(n, 0.01)
     assert sim.graph_stats()["cached"] <= 8
