@@ -156,8 +156,8 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
  *   "graph"     how PerformSimUpdate(n > 1) runs its chain: 0 = plain stream launches; 1 = always as a hipGraph, built on
  *               first use and cached per (length, ping-pong phase); 2 (default) = auto: calls shorter than 16 steps are
  *               plain launches (a graph launch costs the host ~12 us more than a few plain launches).  Longer calls on
- *               small worlds (N x M <= 2.1e8: a step of <= ~40 us, where a replayed node is 0.7-1.9 us cheaper than a
- *               plain launch) replay ONE canonical 32-step chain that is built when the data first reaches the device,
+ *               small worlds (N x M <= 6e7, about N <= 11 000: steps short enough that a replayed node beats a plain
+ *               launch) replay ONE canonical 32-step chain that is built when the data first reaches the device,
  *               with plain launches for the remainder; on larger worlds a chain length runs as plain launches the first
  *               time it is asked for and as a cached hipGraph from the second time on (a replay saves nothing there).
  *               The step size is never baked into a chain: kernels read it from device memory.

@@ -690,15 +690,15 @@ StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchS
 }
 
 // graph = 2 (auto) on small worlds: ONE canonical chain of CANON_STEPS steps starting at phase 0, built when the data
-// first reaches the device (outside any step call) and replayed by every call of 16+ steps: a step or two of plain
-// launches to reach phase 0, whole replays (even length: the phase stays 0), the remainder as plain launches.  A
-// replayed node costs 0.7-1.9 us less than a plain launch below N ~ 10 000 (4.23 -> 4.08 us per step at N = 250,
-// 5.14 -> 4.49 at 1 000, 8.58 -> 6.69 at 4 000, 20.0 -> 18.7 at 10 000: profiles/r02_graph_chunk_probe.txt) and
-// nothing above ~20 000, where a launch's latency hides behind the previous kernel; building the 32-step chain costs
-// 95-150 us once.  So the reference's nbody-bench -- ONE 100-step call per world (bench.c:30-33) -- runs 96 of its 100
-// steps at the replay rate without ever paying for a build inside the call.
+// first reaches the device (outside any step call) and replayed by every call of 32+ steps: one plain step if needed
+// to reach phase 0, whole replays (even length: the phase stays 0), the remainder as plain launches.  A replayed node
+// is a little cheaper than a plain launch while steps are short -- the first 100-step call of a fresh pipeline runs
+// 4.56 vs 4.71 us per step at N = 250, 5.00 vs 5.11 at 1 000, 7.29 vs 7.53 at 4 000, 20.7 vs 20.9 at 10 000, and
+// slightly SLOWER at 20 000 (50.0 vs 48.4): profiles/r02_first_call_probe.txt -- and building the 32-step chain costs
+// 95-150 us once (profiles/r02_graph_chunk_probe.txt), which a one-off call could never win back.  Prebuilt, the
+// reference's nbody-bench -- ONE 100-step call per world (bench.c:30-33) -- runs 96 of its 100 steps at the replay rate.
 constexpr uint32_t CANON_STEPS = 32;
-constexpr double CANON_MAX_PAIRS = 2.1e8;  // N x M up to which a step is short enough (~40 us) for a replay to pay
+constexpr double CANON_MAX_PAIRS = 6.0e7;  // N x M up to which a replay still pays (N ~ 11 000 with galaxy.h ICs)
 
 bool wants_canonical(const SimPipeline *s) {
     return !s->sharded && s->use_graph == 2 && s->n_real > 0 &&
