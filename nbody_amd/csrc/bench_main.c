@@ -15,6 +15,8 @@
  *   --galaxies G   galaxies per universe  (default 2)
  *   --seed S       srand seed             (default 11037)
  *   --own-rng      draw the universes from MakeGalaxiesSeeded(seed + row) instead of libc rand()
+ *   --repeats R    time the K-step call R times on the same world and report the fastest (default 1 = the
+ *                  reference's single timed call; a row of a few hundred microseconds is at the mercy of one OS hiccup)
  * and more columns: interactions/s = N * mass_len * steps / time per backend, and for the GPU the share of the
  * fp32 roofline that is (14 flop per interaction, 157.3 TFLOP/s), then what the chip allows at THIS size:
  *   GPU floor = N * mass_len / 5.3e12 interactions/s  (the rate the step kernel sustains at N = 2^20, i.e. the
@@ -48,15 +50,19 @@ static double seconds_now(void) {
 }
 
 /* one warm-up call, one timed call; returns seconds per step */
-static double time_backend(World *w, UpdateFn update, float dt, uint32_t warmup, uint32_t steps) {
+static double time_backend(World *w, UpdateFn update, float dt, uint32_t warmup, uint32_t steps, uint32_t repeats) {
     /* At least one untimed step always runs, also with --warmup 0: the first UpdateWorld_GPU call carries the
      * upload and the first-touch device setup (stream, HBM buffers, page-locking the World's array), which are
      * not part of a step.  A zero-step call cannot stand in: it is a no-op by contract (world.c:113). */
     update(w, dt, warmup > 0 ? warmup : 1);
-    const double t0 = seconds_now();
-    update(w, dt, steps);
-    const double t1 = seconds_now();
-    return (t1 - t0) / (double)steps;
+    double best = 0.0;
+    for (uint32_t r = 0; r < repeats; r++) {
+        const double t0 = seconds_now();
+        update(w, dt, steps);
+        const double t1 = seconds_now();
+        if (r == 0 || t1 - t0 < best) best = t1 - t0;
+    }
+    return best / (double)steps;
 }
 
 static uint32_t count_massive(const Particle *ps, uint32_t n) {
@@ -71,7 +77,7 @@ int main(int argc, char **argv) {
     bool use_cpu = true, use_gpu = true;
     uint32_t sizes[64];
     uint32_t n_sizes = 0;
-    uint32_t steps = 100, warmup = 10, galaxies = 2;
+    uint32_t steps = 100, warmup = 10, galaxies = 2, repeats = 1;
     unsigned seed = 11037;
     bool own_rng = false;
     float dt = 1.f;
@@ -95,12 +101,14 @@ int main(int argc, char **argv) {
             galaxies = (uint32_t)strtoul(val, NULL, 0), a++;
         } else if (!strcmp(arg, "--seed") && val) {
             seed = (unsigned)strtoul(val, NULL, 0), a++;
+        } else if (!strcmp(arg, "--repeats") && val) {
+            repeats = (uint32_t)strtoul(val, NULL, 0), a++;
         } else if (!strcmp(arg, "--own-rng")) {
             own_rng = true;
         } else {
             fprintf(stderr,
                     "usage: %s [--cpu|--gpu] [--n N]... [--steps K] [--warmup W] [--dt DT] [--galaxies G] [--seed S]"
-                    " [--own-rng]\n",
+                    " [--own-rng] [--repeats R]\n",
                     argv[0]);
             return 2;
         }
@@ -110,6 +118,7 @@ int main(int argc, char **argv) {
         memcpy(sizes, REFERENCE_SIZES, sizeof REFERENCE_SIZES);
     }
     if (steps == 0) steps = 1;
+    if (repeats == 0) repeats = 1;
 
     srand(seed); /* one seed for the whole table, as the reference */
 
@@ -128,12 +137,12 @@ int main(int argc, char **argv) {
         double cpu_s = 0, gpu_s = 0;
         if (use_cpu) {
             World *w = CreateWorld(ps, n);
-            cpu_s = time_backend(w, UpdateWorld_CPU, dt, warmup, steps);
+            cpu_s = time_backend(w, UpdateWorld_CPU, dt, warmup, steps, repeats);
             DestroyWorld(w);
         }
         if (use_gpu) {
             World *w = CreateWorld(ps, n);
-            gpu_s = time_backend(w, UpdateWorld_GPU, dt, warmup, steps);
+            gpu_s = time_backend(w, UpdateWorld_GPU, dt, warmup, steps, repeats);
             DestroyWorld(w);
         }
         printf("\t%7u", n);

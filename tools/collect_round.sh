@@ -14,6 +14,9 @@ NB_HIP_FORCE_SHARDED=1 python -m torch.distributed.run --nnodes=1 --nproc-per-no
   echo "== nbody_amd/lib/nbody-bench (reference harness defaults: srand(11037), 10 warm-up + 100 steps, dt = 1; us/step), MI355X box, OMP_NUM_THREADS=16 =="
   OMP_NUM_THREADS=16 ./nbody_amd/lib/nbody-bench
   echo
+  echo "== the same, GPU column only, fastest of 5 timed 100-step calls per world (--repeats 5) =="
+  ./nbody_amd/lib/nbody-bench --gpu --repeats 5
+  echo
   echo "== oracle/_ref/nbody-bench-ref: the reference's own src/bench.c + src/lib/world.c + sim_cpu.c + galaxy.c, linked against libnbody_hip.so =="
   OMP_NUM_THREADS=16 ./oracle/_ref/nbody-bench-ref
 } > $O/${TAG}_nbody_bench_tables.txt 2>&1; echo "tables rc=$?"
