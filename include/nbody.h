@@ -85,6 +85,17 @@ void UpdateWorld_CPU(World *w, float dt, uint32_t n);
 /* n steps of size dt on the MI355X; returns when they are done (reference nbody.h:73). */
 void UpdateWorld_GPU(World *w, float dt, uint32_t n);
 
+/*
+ * Extension (no reference counterpart): the same World over several GPUs, one process per GPU.  Every rank passes
+ * the same ps[0..size); rank r of nranks steps the r-th 1/P of the particles on its GPU (set with
+ * nb_hip_set_device, include/nbody_hip.h) and the ranks exchange source positions once per step over RCCL.
+ * unique_id128 = the 128 bytes rank 0 got from nb_hip_comm_unique_id(), carried to the other ranks by any means.
+ * All ranks must then make the same World calls in the same order: UpdateWorld_GPU and GetWorldParticles become
+ * collectives (GetWorldParticles returns the full array on every rank), UpdateWorld_CPU steps the full array
+ * redundantly on every rank (same bits everywhere).  nranks == 1 gives an ordinary World.
+ */
+World *CreateWorldSharded(const Particle *ps, uint32_t size, int rank, int nranks, const void *unique_id128);
+
 #ifdef __cplusplus
 }
 #endif

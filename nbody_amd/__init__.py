@@ -78,6 +78,7 @@ NBODY_API = {
     "GetWorldParticles": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "UpdateWorld_CPU": (None, [C.c_void_p, C.c_float, C.c_uint32]),
     "UpdateWorld_GPU": (None, [C.c_void_p, C.c_float, C.c_uint32]),
+    "CreateWorldSharded": (C.c_void_p, [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
     "MakeGalaxies": (C.c_void_p, [C.c_uint32, C.c_uint32]),
     "MakeGalaxiesSeeded": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_uint64]),
 }
@@ -294,10 +295,15 @@ class LocalShardGroup:
 class World:
     """include/nbody.h World, bound 1:1 (CreateWorld / UpdateWorld_CPU / UpdateWorld_GPU / ...)."""
 
-    def __init__(self, particles):
+    def __init__(self, particles, rank=None, nranks=1, unique_id=None):
+        """rank / nranks / unique_id: CreateWorldSharded (extension), one World per process and GPU."""
         a = as_particles(particles)
         self.size = a.shape[0]
-        self._h = nbody_lib().CreateWorld(a.ctypes.data, self.size)
+        if rank is None:
+            self._h = nbody_lib().CreateWorld(a.ctypes.data, self.size)
+        else:
+            idbuf = (C.c_ubyte * UNIQUE_ID_BYTES).from_buffer_copy(unique_id) if unique_id is not None else None
+            self._h = nbody_lib().CreateWorldSharded(a.ctypes.data, self.size, rank, nranks, idbuf)
 
     def close(self):
         if self._h:

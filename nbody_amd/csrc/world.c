@@ -56,7 +56,8 @@ static uint32_t partition_by_mass(Particle *p, uint32_t count) {
     }
 }
 
-World *CreateWorld(const Particle *ps, uint32_t size) {
+/* rank < 0: an ordinary single-GPU World; otherwise the sharded pipeline of include/nbody_hip.h. */
+static World *create_world(const Particle *ps, uint32_t size, int rank, int nranks, const void *unique_id128) {
     World *w = NB_NEW(1, World);
     NB_CHECK(w != NULL, "Failed to alloc World");
     w->particles = NB_NEW(size ? size : 1, Particle);
@@ -65,7 +66,8 @@ World *CreateWorld(const Particle *ps, uint32_t size) {
 
     w->count = size;
     w->massive = partition_by_mass(w->particles, size);
-    w->gpu = CreateSimPipeline((WorldData){.total_len = size, .mass_len = w->massive, .dt = 0.0f});
+    const WorldData data = {.total_len = size, .mass_len = w->massive, .dt = 0.0f};
+    w->gpu = rank < 0 ? CreateSimPipeline(data) : CreateSimPipelineSharded(data, rank, nranks, unique_id128);
     /* this array is what every later Set/GetSimulationData moves: let the pipeline page-lock it when (if) it
      * first touches the GPU.  DestroyWorld destroys the pipeline before freeing the array. */
     nb_hip_note_host_array(w->gpu, w->particles, (uint64_t)size * sizeof(Particle));
@@ -73,6 +75,18 @@ World *CreateWorld(const Particle *ps, uint32_t size) {
     w->host_is_newer = true;    /* the device has seen nothing yet */
     w->device_is_newer = false;
     return w;
+}
+
+World *CreateWorld(const Particle *ps, uint32_t size) { return create_world(ps, size, -1, 1, NULL); }
+
+/*
+ * Extension: one World per process and GPU.  The partition is deterministic, so every rank derives the same
+ * mass_len and the same index order from the same input; the pipeline then owns the rank's 1/P of the receivers
+ * (nb_hip_shard_plan) and the coherence protocol above is unchanged -- Set/Get/Perform are simply collectives.
+ */
+World *CreateWorldSharded(const Particle *ps, uint32_t size, int rank, int nranks, const void *unique_id128) {
+    NB_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "rank %d of %d", rank, nranks);
+    return create_world(ps, size, rank, nranks, unique_id128);
 }
 
 void DestroyWorld(World *w) {

@@ -41,7 +41,8 @@ def test_nbody_library_exports_public_surface():
     names = declared_functions("nbody.h") + declared_functions("galaxy.h")
     assert set(names) == {"CreateWorld", "DestroyWorld", "GetWorldParticles", "UpdateWorld_CPU",
                           "UpdateWorld_GPU", "MakeGalaxies",   # reference nbody.h:61-73, galaxy.h:64
-                          "MakeGalaxiesSeeded"}                # extension: libc-independent draws
+                          "MakeGalaxiesSeeded",                # extension: libc-independent draws
+                          "CreateWorldSharded"}                # extension: one World per process and GPU
     have = exported(nb.NBODY_SO)
     assert not [n for n in names if n not in have]
 

@@ -838,6 +838,36 @@ print("RCCL-EVIDENCE-OK")
     assert r.returncode == 0 and "RCCL-EVIDENCE-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+def test_sharded_world_surface_with_one_rccl_rank(golden):
+    """CreateWorldSharded (include/nbody.h extension) with the one rank this box has: the World's coherence protocol on
+    top of the RCCL pipeline -- GPU steps, collective read-back, a CPU step on the gathered array, re-upload -- gives
+    the ordinary World's state."""
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, %(root)r)
+import nbody_amd as nb
+ic = np.fromfile(os.path.join(%(root)r, "tests/golden/ic_1024.bin"), dtype=np.float32).reshape(-1, 8)
+def drive(w):
+    out = []
+    w.update_gpu(0.01, 2); out.append(w.particles())
+    w.update_cpu(0.01, 1); w.update_gpu(0.01, 3); out.append(w.particles())
+    w.update_gpu(0.005, 1); w.update_gpu(0.005, 1); out.append(w.particles())
+    w.close()
+    return out
+plain = drive(nb.World(ic))
+nb.hip_lib()
+shard = drive(nb.World(ic, rank=0, nranks=1, unique_id=nb.comm_unique_id()))
+for a, b in zip(plain, shard):
+    d = a[:, 0:2].astype(np.float64) - b[:, 0:2]
+    assert np.linalg.norm(d) / np.linalg.norm(a[:, 0:2].astype(np.float64)) <= 1e-7
+    assert np.array_equal(a[:, 6:8], b[:, 6:8])
+print("SHARDED-WORLD-OK")
+''' % {"root": nb.ROOT}
+    env = dict(os.environ, NB_HIP_FORCE_SHARDED="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "SHARDED-WORLD-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 @pytest.mark.parametrize("mode", ["plain", "sharded_graph"])
 def test_bench_under_torchrun_with_one_forced_sharded_rank(mode):
     """bench.py exactly as the driver launches it for N > 1 (python -m torch.distributed.run ... bench.py --gpus N),
