@@ -130,6 +130,9 @@ int nb_hip_comm_info(const SimPipeline *sim, int *nranks, int *rank, int *device
  * sim_gpu.c:268-284, so a changed dt never rebuilds or patches a cached chain). */
 uint32_t nb_hip_graph_stats(const SimPipeline *sim, uint32_t *dt_uploads);
 
+/* The source-slice granule ("unit" knob) the last step launch used. */
+int nb_hip_launch_unit(const SimPipeline *sim);
+
 /* hipRuntimeGetVersion() of the HIP runtime this process actually bound (0 when it cannot be asked). */
 int nb_hip_runtime_version(void);
 
@@ -150,6 +153,9 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
  *               builds); w = 1 makes the summation order independent of the launch geometry
  *   "split"     workgroups per receiver tile, each over 1/split of the sources (a second small kernel adds
  *               the parts and integrates): 0 = auto (fills the chip / lands on a round boundary), else 1..16
+ *   "unit"      granule of the source slicing: a wave's slice is a whole number of `unit` sources.  0 = auto (64; 32, 16
+ *               or 8 for latency-bound launches whose source parts hold fewer 64-source chunks than a workgroup has
+ *               waves), else 8, 16, 32 or 64
  *   "passes"    launches per step over consecutive source sub-ranges, chained through acc[]: 0 = auto (each
  *               pass's sources fit one XCD's L2, so they are fetched once per pass instead of once per round:
  *               23x less memory-side traffic at N = 2^20, same speed), else 1..64

@@ -56,6 +56,7 @@ HIP_API = {
                                    C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_char_p, C.c_uint32]),
     "nb_hip_graph_stats": (C.c_uint32, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "nb_hip_runtime_version": (C.c_int, []),
+    "nb_hip_launch_unit": (C.c_int, [C.c_void_p]),
     "nb_hip_note_host_array": (None, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "nb_hip_configure": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "nb_hip_launch_shape": (None, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
@@ -257,7 +258,7 @@ class SimPipeline:
         k, w, v, sp, g = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_uint32()
         hip_lib().nb_hip_launch_shape(self._h, C.byref(k), C.byref(w), C.byref(v), C.byref(sp), C.byref(g))
         return {"k": k.value, "w": w.value, "variant": "smem" if v.value else "lds", "split": sp.value,
-                "workgroups": g.value}
+                "workgroups": g.value, "unit": int(hip_lib().nb_hip_launch_unit(self._h))}
 
 
 class LocalShardGroup:

@@ -51,6 +51,11 @@ struct StepParams {
     // workgroup count near a round boundary (see choose_shape).
     float2 *parts;
     uint32_t split;
+    // granule of the source slicing: a wave's slice is a whole number of `unit` sources (64, or 32 / 16 / 8 for
+    // latency-bound launches whose parts hold fewer 64-source chunks than the workgroup has waves -- with 64 only, a
+    // part of 6 chunks keeps 6 of 16 waves busy).  Slices stay 8-aligned, so the scalar loads keep their alignment and
+    // both source routes walk them in the same order.  Two-range (overlapped) steps always use 64.
+    uint32_t unit;
 };
 
 struct LaunchShape {
@@ -58,6 +63,7 @@ struct LaunchShape {
     int w;        // waves per workgroup = source slices: 1, 4, 8, 16 (2 in tuning builds)
     int variant;  // VARIANT_*
     int split;    // workgroups per receiver tile (source parts): 1 .. MAX_SPLIT
+    int unit;     // sources per slice granule: 64 (default), 32, 16, 8
 };
 
 constexpr int MAX_SPLIT = 16;

@@ -296,14 +296,18 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
     const uint32_t n0 = p.src_end[0] - p.src_begin[0];
     const uint32_t n1 = p.src_end[1] - p.src_begin[1];
     const uint32_t total = n0 + n1;
-    const uint32_t nchunks = (total + CHUNK - 1) / CHUNK;
-    // this workgroup's part of the chunks (all of them unless the step is split), then this wave's slice of it
-    const uint32_t per_part = (nchunks + p.split - 1) / p.split;
-    const uint32_t part_lo = min(blockIdx.y * per_part, nchunks);
-    const uint32_t part_hi = min(part_lo + per_part, nchunks);
+    // this workgroup's part of the sources (all of them unless the step is split), then this wave's slice of it, both
+    // in whole granules of p.unit sources (64 = one tile; finer for latency-bound launches, see StepParams::unit)
+    const uint32_t unit = p.unit;
+    const uint32_t nunits = (total + unit - 1) / unit;
+    const uint32_t per_part = (nunits + p.split - 1) / p.split;
+    const uint32_t part_lo = min(blockIdx.y * per_part, nunits);
+    const uint32_t part_hi = min(part_lo + per_part, nunits);
     const uint32_t per_wave = (part_hi - part_lo + W - 1) / W;
-    const uint32_t c_lo = min(part_lo + wid * per_wave, part_hi);
-    const uint32_t c_hi = min(c_lo + per_wave, part_hi);
+    const uint32_t u_lo = min(part_lo + wid * per_wave, part_hi);
+    const uint32_t u_hi = min(u_lo + per_wave, part_hi);
+    const uint32_t v_lo = u_lo * unit;                // first source of the slice: a multiple of 8
+    const uint32_t v_hi = min(u_hi * unit, total);    // one past its last source
 
     if constexpr (VARIANT == VARIANT_LDS) {
         float(*T)[3 * CHUNK] = tile[wid];
@@ -316,30 +320,45 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
             sp = p.src_pos[j];                 // 512 B per wave, coalesced
             sg = live ? p.src_gm[j] : 0.0f;    // pad sources: a real position, zero mass
         };
-        if (c_lo < c_hi) fetch(c_lo);
-        int buf = 0;
-        for (uint32_t c = c_lo; c < c_hi; c++) {
-            *reinterpret_cast<float2 *>(&T[buf][2 * lane]) = sp;  // ds_write_b64
-            T[buf][2 * CHUNK + lane] = sg;
-            if (c + 1 < c_hi) fetch(c + 1);  // next tile's HBM/L2 latency hides under this tile's math
-            // LDS executes one wave's accesses in order; this only stops the compiler from reordering
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int jj = 0; jj < CHUNK; jj += 8) {
-                // broadcast ds_read_b128: every lane reads the same 16 bytes; (x, y) pairs land in aligned VGPR pairs
-                const v16f P = *reinterpret_cast<const v16f *>(&T[buf][2 * jj]);
-                const v8f G = *reinterpret_cast<const v8f *>(&T[buf][2 * CHUNK + jj]);
-                interact8<K, false>(R, P, G);
+        if (v_lo < v_hi) {
+            const uint32_t c_first = v_lo / CHUNK, c_last = (v_hi - 1) / CHUNK;
+            fetch(c_first);
+            int buf = 0;
+            uint32_t groups_done = 0;  // 8-source groups since the slice began: a summation block closes every 32
+            for (uint32_t c = c_first; c <= c_last; c++) {
+                *reinterpret_cast<float2 *>(&T[buf][2 * lane]) = sp;  // ds_write_b64
+                T[buf][2 * CHUNK + lane] = sg;
+                if (c < c_last) fetch(c + 1);  // next tile's HBM/L2 latency hides under this tile's math
+                // LDS executes one wave's accesses in order; this only stops the compiler from reordering
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // the part of this tile that belongs to the slice (whole tile unless the slice granule is finer)
+                const uint32_t j_lo = c == c_first ? v_lo - c * CHUNK : 0u;
+                const uint32_t j_hi = c == c_last ? v_hi - c * CHUNK : (uint32_t)CHUNK;  // a ragged end reads zero-mass pads
+                if (j_lo == 0 && j_hi == CHUNK) {
+                    for (int jj = 0; jj < CHUNK; jj += 8) {
+                        // broadcast ds_read_b128: every lane reads the same 16 bytes; (x, y) pairs land in aligned VGPR pairs
+                        const v16f P = *reinterpret_cast<const v16f *>(&T[buf][2 * jj]);
+                        const v8f G = *reinterpret_cast<const v8f *>(&T[buf][2 * CHUNK + jj]);
+                        interact8<K, false>(R, P, G);
+                    }
+                    groups_done += CHUNK / 8;
+                    if ((groups_done & (8u * CLOSE_EVERY - 1)) == 0) R.close_chunk();
+                } else {
+                    for (uint32_t jj = j_lo; jj < j_hi; jj += 8) {
+                        const v16f P = *reinterpret_cast<const v16f *>(&T[buf][2 * jj]);
+                        const v8f G = *reinterpret_cast<const v8f *>(&T[buf][2 * CHUNK + jj]);
+                        interact8<K, false>(R, P, G);
+                        if ((++groups_done & (8u * CLOSE_EVERY - 1)) == 0) R.close_chunk();
+                    }
+                }
+                buf ^= 1;
             }
-            if (((c - c_lo) & (CLOSE_EVERY - 1)) == CLOSE_EVERY - 1) R.close_chunk();
-            buf ^= 1;
+            if (groups_done & (8u * CLOSE_EVERY - 1)) R.close_chunk();  // a short last block
         }
-        if ((c_hi - c_lo) & (CLOSE_EVERY - 1)) R.close_chunk();  // a short last block
     } else {
         // scalar-cache route: indices are wave-uniform, the loads become s_load_dwordx8/x16
-        const uint32_t v_lo = c_lo * CHUNK;
-        const uint32_t v_hi = min(c_hi * CHUNK, total);
 #pragma unroll
         for (int range = 0; range < 2; range++) {
             // intersection of [v_lo, v_hi) with this range, as indices of the source arrays
@@ -525,37 +544,44 @@ const void *pick(int k, int w) {
 }  // namespace
 
 // Launches that do not even fill the chip once with K = 2 / W = 16 workgroups (fewer than 65 536 receivers on 256
-// CUs) are priced in microseconds by a model fitted to exhaustive (K, W, split) scans at N = 1 000 ... 50 000
-// (tools/sweep_shapes.py, profiles/r01_sweep15_shape_scan_small_n.txt).  There a wave is latency-bound, not
-// issue-bound: alone on its SIMD it needs LAT us per 64-source chunk and receiver set (a serial dependency chain),
-// and only beyond LAT / THR ~ 2.3 waves per SIMD does the chunk time grow with occupancy.  Cutting the sources into
-// more parts shortens every wave's chain, so small launches want splits the big-launch model would never pay for:
-// N = 4 000 runs 6.9 us per step with 4 parts instead of 10.1 us unsplit.
-static double small_launch_cost_us(uint32_t n_recv, uint32_t n_src, int k, int w, int sp, int cus) {
-    constexpr double LAT = 1.77, THR = 0.756, K1 = 1.023, MIX = 0.26, TAIL = 0.0217;
-    constexpr double FINISH = 1.30, FINISH_PER_PART = 0.0987, PARTS_BYTES_PER_US = 2.0e6;
-    const uint32_t chunks = (n_src + CHUNK - 1) / CHUNK;
+// CUs) are priced in microseconds by a model fitted to exhaustive (K, W, split, unit) scans at N = 250 ... 50 000
+// (tools/sweep_shapes.py; profiles/r02_sweep_shapes_units.txt holds the scan, 3 360 timed shapes).  There a wave is
+// latency-bound, not issue-bound: alone on its SIMD it needs LAT us per 64-source chunk and receiver set (a serial
+// dependency chain), and only beyond ~2 waves per SIMD does the chunk time grow with occupancy -- at THR us per wave,
+// worse (factor A) the emptier the SIMD, and worse again for K = 1 (K1A).  Every wave also costs UFIX chunks of fixed
+// work (launch, receiver loads, the LDS reduction), which is what stops the split from growing without bound, and a
+// split adds the finish kernel.  Cutting the sources into more parts and finer granules shortens every wave's chain, so
+// small launches want shapes the big-launch model would never pay for: N = 250 runs 3.2 us per step with 16 waves of 8
+// sources instead of 4.6 us with two waves of 64, N = 2 000 5.4 instead of 6.7, N = 4 000 6.8 with 8 parts of 256-thread
+// workgroups.  Mean regret of the model's pick against the scan's best: 1.7 % (worst 4.4 %).
+static double small_launch_cost_us(uint32_t n_recv, uint32_t n_src, int k, int w, int sp, int unit, int cus) {
+    constexpr double LAT = 1.575, THR = 0.7545, K1 = 0.987, K1A = 0.178, A = 0.179, MIX = 0.874;
+    constexpr double FINISH = 2.08, W4 = 1.035, UFIX = 0.15, BASE = 2.27;
+    // the longest wave slice of a workgroup, in 64-source chunks (a fraction of one when the slice granule is finer)
+    const uint32_t granules = (n_src + unit - 1) / unit;
     const uint64_t groups = ((uint64_t)n_recv + WAVE * k - 1) / (WAVE * k) * (uint64_t)sp;
     const uint64_t capacity = (uint64_t)cus * (32 / w);
     const uint64_t full = groups / capacity, left = groups % capacity;
-    const uint32_t part_chunks = (chunks + sp - 1) / sp;
-    const uint32_t wave_chunks = (part_chunks + w - 1) / w;
-    const double units = (double)k * (wave_chunks ? wave_chunks : 1);
-    const double f = k == 1 ? K1 : 1.0;
-    const double unit_full = 8.0 * THR * f;  // a chunk with 8 waves on every SIMD
-    double t = (double)full * units * unit_full;
+    const uint32_t part_granules = (granules + sp - 1) / sp;
+    const uint32_t wave_granules = (part_granules + w - 1) / w;
+    const double units = (double)k * (wave_granules ? wave_granules : 1) * (double)unit / (double)CHUNK + UFIX;
+    auto chunk_time = [&](double occ) {  // us per chunk and receiver set with `occ` waves on every SIMD
+        const double f = k == 1 ? K1 + K1A * (8.0 - occ) / 8.0 : 1.0;
+        const double busy = occ * THR * f * (1.0 + A * (8.0 - occ) / 8.0);
+        return LAT > busy ? LAT : busy;
+    };
+    double t = (double)full * units * chunk_time(8.0);
     if (left) {
         // the busiest CU holds ceil(left / CUs) workgroups of w waves on its 4 SIMDs
         double occ = (w / 4.0) * (double)((left + cus - 1) / cus);
         if (occ > 8.0) occ = 8.0;
-        const double lock = units * (LAT > occ * THR * f ? LAT : occ * THR * f);  // runs after the full rounds
-        const double fluid = units * unit_full * (double)left / (double)capacity;  // packs in behind them
+        const double lock = units * chunk_time(occ);                                    // runs after the full rounds
+        const double fluid = units * chunk_time(8.0) * (double)left / (double)capacity;  // packs in behind them
         t += full ? MIX * lock + (1.0 - MIX) * fluid : lock;
     }
-    if (full) t += TAIL * units * unit_full;
-    if (sp > 1) t += FINISH + FINISH_PER_PART * sp + (double)n_recv * (24.0 + 8.0 * sp) / PARTS_BYTES_PER_US;
-    if (w == 4) t *= 1.05;  // 4-wave workgroups: the fit alone overrates them (N = 6 000: 12.0 us picked, 10.3 best)
-    return t;
+    if (sp > 1) t += FINISH;
+    if (w == 4) t *= W4;
+    return t + BASE;  // what every step pays whatever its shape (dispatch, kernel boundary): keeps ties ties
 }
 
 LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int compute_units) {
@@ -577,29 +603,41 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
             if (want.w != 0 && want.w != w) continue;
             for (int sp = 1; sp <= MAX_SPLIT; sp++) {
                 if (want.split != 0 && want.split != sp) continue;
-                double cost;
-                if (small) {
-                    cost = small_launch_cost_us(n_recv, n_src, k, w, sp, compute_units);
-                } else {
-                    const uint64_t groups = ((uint64_t)n_recv + WAVE * k - 1) / (WAVE * k) * (uint64_t)sp;
-                    const uint64_t capacity = (uint64_t)compute_units * (32 / w);  // 8 waves per SIMD at <= 64 VGPRs
-                    const uint64_t rounds = (groups + capacity - 1) / capacity;
-                    const uint32_t part_chunks = (chunks + sp - 1) / sp;
-                    const uint32_t wave_chunks = (part_chunks + w - 1) / w;
-                    // + 1 chunk-equivalent per workgroup for prologue/epilogue; + TAIL rounds per launch for ramp-up
-                    // and the ragged end (measured: 2-round launches run 4.5 % over, 16-round ones 0.1 % over:
-                    // profiles/r01_shard_overhead_split.txt); a split adds the finish kernel and the parts traffic
-                    constexpr double TAIL = 0.13;
-                    cost = ((double)rounds + TAIL) * ((double)k * (wave_chunks ? wave_chunks : 1) + 1.0);
-                    if (sp > 1) cost += 3.0 + 0.02 * sp;
-                    if (w < 16) cost *= 1.01;
-                    if (k == 1) cost *= 1.25;  // measured: K = 1 is slower per interaction at large N
-                }
-                if (best_cost < 0.0 || cost < best_cost * 0.999) {
-                    best_cost = cost;
-                    best.k = k;
-                    best.w = w;
-                    best.split = sp;
+                // small launches: 1024-thread workgroups exactly while the whole launch is a handful of unsplit tiles
+                // (16 waves per tile beat 8 there: 4.2 vs 4.6 us at N = 800); beyond that 256- and 512-thread
+                // workgroups pack better, and the model overrates W = 16
+                const bool few_unsplit_tiles = sp == 1 && ((uint64_t)n_recv + WAVE * k - 1) / (WAVE * k) <= 24;
+                if (small && want.w == 0 && (w == 16) != few_unsplit_tiles) continue;
+                // slice granule: 64 unless the launch is latency-bound; a finer one only has to win where a part holds
+                // fewer chunks than the workgroup has waves, and ties keep the coarser granule (64 first)
+                for (int unit = CHUNK; unit >= 8; unit /= 2) {
+                    if (want.unit != 0 && want.unit != unit) continue;
+                    if (!small && want.unit == 0 && unit != CHUNK) continue;
+                    double cost;
+                    if (small) {
+                        cost = small_launch_cost_us(n_recv, n_src, k, w, sp, unit, compute_units);
+                    } else {
+                        const uint64_t groups = ((uint64_t)n_recv + WAVE * k - 1) / (WAVE * k) * (uint64_t)sp;
+                        const uint64_t capacity = (uint64_t)compute_units * (32 / w);  // 8 waves per SIMD at <= 64 VGPRs
+                        const uint64_t rounds = (groups + capacity - 1) / capacity;
+                        const uint32_t part_chunks = (chunks + sp - 1) / sp;
+                        const uint32_t wave_chunks = (part_chunks + w - 1) / w;
+                        // + 1 chunk-equivalent per workgroup for prologue/epilogue; + TAIL rounds per launch for ramp-up
+                        // and the ragged end (measured: 2-round launches run 4.5 % over, 16-round ones 0.1 % over:
+                        // profiles/r01_shard_overhead_split.txt); a split adds the finish kernel and the parts traffic
+                        constexpr double TAIL = 0.13;
+                        cost = ((double)rounds + TAIL) * ((double)k * (wave_chunks ? wave_chunks : 1) + 1.0);
+                        if (sp > 1) cost += 3.0 + 0.02 * sp;
+                        if (w < 16) cost *= 1.01;
+                        if (k == 1) cost *= 1.25;  // measured: K = 1 is slower per interaction at large N
+                    }
+                    if (best_cost < 0.0 || cost < best_cost * 0.999) {
+                        best_cost = cost;
+                        best.k = k;
+                        best.w = w;
+                        best.split = sp;
+                        best.unit = unit;
+                    }
                 }
             }
         }
@@ -608,6 +646,7 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
         best.k = want.k ? want.k : 2;
         best.w = want.w ? want.w : 16;
         best.split = want.split ? want.split : 1;
+        best.unit = want.unit ? want.unit : CHUNK;
     }
     return best;
 }

@@ -243,7 +243,7 @@ struct StepGraph {
     std::vector<hipGraphNode_t> nodes;  // one kernel node per launch, in order
     std::vector<nb::StepParams> params; // what each node currently holds
     int phase = -1;                     // which pos buffer the chain reads first
-    nb::LaunchShape shape = {0, 0, 0, 0};
+    nb::LaunchShape shape = {0, 0, 0, 0, 0};
     uint64_t last_use = 0;              // for eviction: the cache holds at most GRAPH_CACHE_MAX chains
 };
 
@@ -349,7 +349,8 @@ struct SimPipeline {
     std::vector<uint32_t> seen_chains;                  // chain lengths already run once as plain launches
     int want_passes = 0;  // source passes per step (0 = auto: keep each pass's sources within one XCD's L2)
     double first_gather_ms = 0.0;  // sharded: device time of the probe all-gather at creation (includes lazy setup)
-    nb::LaunchShape last_shape = {0, 0, 0, 0};
+    nb::LaunchShape last_shape = {0, 0, 0, 0, 0};
+    int want_unit = 0;  // source-slice granule: 0 = auto, else 64 / 32 / 16 / 8
     uint32_t last_groups = 0;
 
     std::vector<StepGraph> graphs;
@@ -505,7 +506,7 @@ void materialize(SimPipeline *s) {
 uint32_t passes_for(const SimPipeline *s, const nb::StepParams &p);
 
 nb::LaunchShape resolve_shape(SimPipeline *s) {
-    nb::LaunchShape want = {s->want_k, s->want_w, s->want_variant, s->want_split};
+    nb::LaunchShape want = {s->want_k, s->want_w, s->want_variant, s->want_split, s->want_unit};
     // the model sees one launch: with source passes that is 1/passes of the sources
     nb::StepParams probe;
     memset(&probe, 0, sizeof probe);
@@ -558,12 +559,15 @@ nb::StepParams whole_step(const SimPipeline *s, int in, float dt) {
     p.flags = 0;
     p.parts = nullptr;
     p.split = 1;
+    p.unit = 64;
     return p;
 }
 
 nb::StepParams shaped(const SimPipeline *s, nb::StepParams p, nb::LaunchShape sh) {
     p.split = sh.split > 1 ? (uint32_t)sh.split : 1u;
     p.parts = p.split > 1 ? s->parts : nullptr;
+    // finer slice granules only for single-range steps (the overlapped sharded step walks two ranges: 64 there)
+    p.unit = (sh.unit >= 8 && sh.unit <= 64 && p.src_end[1] == p.src_begin[1]) ? (uint32_t)sh.unit : 64u;
     return p;
 }
 
@@ -641,7 +645,7 @@ void fill_node(hipKernelNodeParams &kp, void **args, const void *fn, dim3 grid, 
 StepGraph *find_graph(SimPipeline *s, uint32_t n, uint32_t passes, nb::LaunchShape sh, int phase) {
     for (auto &c : s->graphs)
         if (c.n == n && c.passes == passes && c.phase == phase && c.shape.k == sh.k && c.shape.w == sh.w &&
-            c.shape.variant == sh.variant && c.shape.split == sh.split)
+            c.shape.variant == sh.variant && c.shape.split == sh.split && c.shape.unit == sh.unit)
             return &c;
     return nullptr;
 }
@@ -869,7 +873,7 @@ void sharded_step(SimPipeline *s, nb::LaunchShape sh, float dt, hipStream_t cs, 
 StepGraph *capture_sharded_chain(SimPipeline *s, uint32_t n, float dt, nb::LaunchShape sh) {
     for (auto &c : s->graphs)
         if (c.n == n && c.phase == s->cur && c.shape.k == sh.k && c.shape.w == sh.w &&
-            c.shape.variant == sh.variant && c.shape.split == sh.split) {
+            c.shape.variant == sh.variant && c.shape.split == sh.split && c.shape.unit == sh.unit) {
             c.last_use = ++s->use_clock;
             return &c;
         }
@@ -1030,6 +1034,8 @@ SimPipeline *CreateSimPipeline(WorldData data) {
     if (w) s->want_w = atoi(w);
     const char *ps = getenv("NB_HIP_PASSES");
     if (ps) s->want_passes = atoi(ps);
+    const char *un = getenv("NB_HIP_UNIT");
+    if (un) s->want_unit = atoi(un);
     const char *sp = getenv("NB_HIP_SPLIT");
     if (sp) s->want_split = atoi(sp);
     const char *rb = getenv("NB_HIP_READBACK");
@@ -1130,7 +1136,7 @@ SimPipeline *CreateSimPipelineShardedWith(WorldData data, int rank, int nranks, 
 }
 
 void nb_hip_plan_launch(uint32_t n_recv, uint32_t n_src, int compute_units, int *k, int *w, int *split, uint32_t *workgroups) {
-    const nb::LaunchShape sh = nb::choose_shape({0, 0, nb::VARIANT_SMEM, 0}, n_recv, n_src, compute_units);
+    const nb::LaunchShape sh = nb::choose_shape({0, 0, nb::VARIANT_SMEM, 0, 0}, n_recv, n_src, compute_units);
     if (k) *k = sh.k;
     if (w) *w = sh.w;
     if (split) *split = sh.split;
@@ -1377,6 +1383,11 @@ uint32_t nb_hip_graph_stats(const SimPipeline *s, uint32_t *patches) {
     return (uint32_t)s->graphs.size();
 }
 
+int nb_hip_launch_unit(const SimPipeline *s) {
+    NB_ASSERT(s != nullptr, "NULL pipeline");
+    return s->last_shape.unit;
+}
+
 int nb_hip_runtime_version(void) {
     int v = 0;
     if (hipRuntimeGetVersion(&v) != hipSuccess) return 0;
@@ -1413,6 +1424,10 @@ int nb_hip_configure(SimPipeline *s, const char *key, int value) {
         NB_ASSERT(value >= 0 && value <= nb::MAX_SPLIT, "split must be 0 (auto) .. %d, got %d", nb::MAX_SPLIT, value);
         old = s->want_split;
         s->want_split = value;
+    } else if (!strcmp(key, "unit")) {
+        NB_ASSERT(value == 0 || value == 8 || value == 16 || value == 32 || value == 64, "unit must be 0, 8, 16, 32 or 64, got %d", value);
+        old = s->want_unit;
+        s->want_unit = value;
     } else if (!strcmp(key, "graph")) {
         NB_ASSERT(value >= 0 && value <= 2, "graph must be 0 (never), 1 (always) or 2 (from the second use), got %d", value);
         old = s->use_graph;

@@ -134,14 +134,15 @@ def test_launch_plan_round_boundaries_and_splits():
         assert p["split"] > 1 and p["workgroups"] == -(-n // (64 * p["k"])) * p["split"]    # off a boundary: split
         rounds = -(-p["workgroups"] // (256 * 32 // p["w"]))
         assert p["workgroups"] / (rounds * 256 * 32 // p["w"]) > 0.9                          # last round nearly full
-    for n, m in ((250, 119), (1000, 485), (2000, 967)):
+    for n, m in ((250, 119), (500, 244), (800, 386)):
         p = nb.plan_launch(n, m)
-        assert p["k"] == 1 and p["split"] == 1                                              # launch-bound: simplest
-    assert nb.plan_launch(20000, 9956)["split"] > 1                                         # unsplit: 69 us, split: 46 us
-    for n, m in ((3000, 1467), (4096, 1989), (6000, 2957)):
+        assert (p["k"], p["w"], p["split"]) == (1, 16, 1)      # a handful of tiles: 16 waves on each, unsplit (finer granules)
+    assert nb.plan_launch(20000, 9956)["split"] > 1                                         # unsplit: 69 us, split: 45 us
+    for n, m in ((2000, 967), (3000, 1467), (4096, 1989), (6000, 2957), (10000, 4917)):
         p = nb.plan_launch(n, m)
-        # latency-bound: every wave's serial chain is cut short by splitting the sources (10.1 -> 6.9 us at N = 4000)
-        assert p["k"] == 1 and 3 <= p["split"] <= 8
+        # latency-bound: every wave's serial chain is cut short by splitting the sources over many small workgroups
+        # (N = 4000: 10.4 us unsplit with 1024-thread workgroups, 6.8 us with 8 parts of 256- or 512-thread ones)
+        assert p["w"] in (4, 8) and 4 <= p["split"] <= 16
     for n, m in ((1, 0), (1, 1), (64, 64), (0, 0), (4194304, 2100000), (123457, 7)):
         p = nb.plan_launch(n, m)
         assert p["k"] in (1, 2) and p["w"] in (4, 8, 16) and 1 <= p["split"] <= 16
