@@ -155,7 +155,8 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
  *               the parts and integrates): 0 = auto (fills the chip / lands on a round boundary), else 1..16
  *   "unit"      granule of the source slicing: a wave's slice is a whole number of `unit` sources.  0 = auto (64; 32, 16
  *               or 8 for latency-bound launches whose source parts hold fewer 64-source chunks than a workgroup has
- *               waves), else 8, 16, 32 or 64
+ *               waves), else 8, 16, 32 or 64.  The LDS route ("variant" 0) always uses 64; the two routes give the
+ *               same bits whenever the granule is 64
  *   "passes"    launches per step over consecutive source sub-ranges, chained through acc[]: 0 = auto (each
  *               pass's sources fit one XCD's L2, so they are fetched once per pass instead of once per round:
  *               23x less memory-side traffic at N = 2^20, same speed), else 1..64

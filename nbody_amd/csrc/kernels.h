@@ -53,8 +53,9 @@ struct StepParams {
     uint32_t split;
     // granule of the source slicing: a wave's slice is a whole number of `unit` sources (64, or 32 / 16 / 8 for
     // latency-bound launches whose parts hold fewer 64-source chunks than the workgroup has waves -- with 64 only, a
-    // part of 6 chunks keeps 6 of 16 waves busy).  Slices stay 8-aligned, so the scalar loads keep their alignment and
-    // both source routes walk them in the same order.  Two-range (overlapped) steps always use 64.
+    // part of 6 chunks keeps 6 of 16 waves busy).  Slices stay 8-aligned, so the scalar loads keep their alignment.
+    // Scalar-cache route only: the LDS route stages whole 64-source tiles and always runs with 64 -- the two routes
+    // give the same bits whenever the granule is 64.  Two-range (overlapped) steps always use 64.
     uint32_t unit;
 };
 

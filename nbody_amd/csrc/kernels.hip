@@ -320,43 +320,29 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
             sp = p.src_pos[j];                 // 512 B per wave, coalesced
             sg = live ? p.src_gm[j] : 0.0f;    // pad sources: a real position, zero mass
         };
-        if (v_lo < v_hi) {
-            const uint32_t c_first = v_lo / CHUNK, c_last = (v_hi - 1) / CHUNK;
-            fetch(c_first);
-            int buf = 0;
-            uint32_t groups_done = 0;  // 8-source groups since the slice began: a summation block closes every 32
-            for (uint32_t c = c_first; c <= c_last; c++) {
-                *reinterpret_cast<float2 *>(&T[buf][2 * lane]) = sp;  // ds_write_b64
-                T[buf][2 * CHUNK + lane] = sg;
-                if (c < c_last) fetch(c + 1);  // next tile's HBM/L2 latency hides under this tile's math
-                // LDS executes one wave's accesses in order; this only stops the compiler from reordering
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // the part of this tile that belongs to the slice (whole tile unless the slice granule is finer)
-                const uint32_t j_lo = c == c_first ? v_lo - c * CHUNK : 0u;
-                const uint32_t j_hi = c == c_last ? v_hi - c * CHUNK : (uint32_t)CHUNK;  // a ragged end reads zero-mass pads
-                if (j_lo == 0 && j_hi == CHUNK) {
-                    for (int jj = 0; jj < CHUNK; jj += 8) {
-                        // broadcast ds_read_b128: every lane reads the same 16 bytes; (x, y) pairs land in aligned VGPR pairs
-                        const v16f P = *reinterpret_cast<const v16f *>(&T[buf][2 * jj]);
-                        const v8f G = *reinterpret_cast<const v8f *>(&T[buf][2 * CHUNK + jj]);
-                        interact8<K, false>(R, P, G);
-                    }
-                    groups_done += CHUNK / 8;
-                    if ((groups_done & (8u * CLOSE_EVERY - 1)) == 0) R.close_chunk();
-                } else {
-                    for (uint32_t jj = j_lo; jj < j_hi; jj += 8) {
-                        const v16f P = *reinterpret_cast<const v16f *>(&T[buf][2 * jj]);
-                        const v8f G = *reinterpret_cast<const v8f *>(&T[buf][2 * CHUNK + jj]);
-                        interact8<K, false>(R, P, G);
-                        if ((++groups_done & (8u * CLOSE_EVERY - 1)) == 0) R.close_chunk();
-                    }
-                }
-                buf ^= 1;
+        // whole 64-source tiles only: this route always runs with the 64-source granule (choose_shape), so the slice
+        // is [c_lo, c_hi) tiles and the last one may be ragged (pads: a real position, zero mass)
+        const uint32_t c_lo = v_lo / CHUNK, c_hi = (v_hi + CHUNK - 1) / CHUNK;
+        if (c_lo < c_hi) fetch(c_lo);
+        int buf = 0;
+        for (uint32_t c = c_lo; c < c_hi; c++) {
+            *reinterpret_cast<float2 *>(&T[buf][2 * lane]) = sp;  // ds_write_b64
+            T[buf][2 * CHUNK + lane] = sg;
+            if (c + 1 < c_hi) fetch(c + 1);  // next tile's HBM/L2 latency hides under this tile's math
+            // LDS executes one wave's accesses in order; this only stops the compiler from reordering
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int jj = 0; jj < CHUNK; jj += 8) {
+                // broadcast ds_read_b128: every lane reads the same 16 bytes; (x, y) pairs land in aligned VGPR pairs
+                const v16f P = *reinterpret_cast<const v16f *>(&T[buf][2 * jj]);
+                const v8f G = *reinterpret_cast<const v8f *>(&T[buf][2 * CHUNK + jj]);
+                interact8<K, false>(R, P, G);
             }
-            if (groups_done & (8u * CLOSE_EVERY - 1)) R.close_chunk();  // a short last block
+            if (((c - c_lo) & (CLOSE_EVERY - 1)) == CLOSE_EVERY - 1) R.close_chunk();
+            buf ^= 1;
         }
+        if ((c_hi - c_lo) & (CLOSE_EVERY - 1)) R.close_chunk();  // a short last block
     } else {
         // scalar-cache route: indices are wave-uniform, the loads become s_load_dwordx8/x16
 #pragma unroll
@@ -612,6 +598,7 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
                 // fewer chunks than the workgroup has waves, and ties keep the coarser granule (64 first)
                 for (int unit = CHUNK; unit >= 8; unit /= 2) {
                     if (want.unit != 0 && want.unit != unit) continue;
+                    if (want.variant == VARIANT_LDS && unit != CHUNK) continue;  // the LDS route stages whole 64-source tiles
                     if (!small && want.unit == 0 && unit != CHUNK) continue;
                     double cost;
                     if (small) {
@@ -648,6 +635,7 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
         best.split = want.split ? want.split : 1;
         best.unit = want.unit ? want.unit : CHUNK;
     }
+    if (want.variant == VARIANT_LDS) best.unit = CHUNK;
     return best;
 }
 

@@ -326,8 +326,9 @@ def test_lds_and_smem_variants_agree_bitwise(golden, k, w):
     # same source order per wave slice; the LDS tail tile's zero-mass pads add exact zeros
     part, m = ob.partition(golden("ic_4096.bin"))
     a = run(part, m, 2, 0.01, variant=0, k=k, w=w)
-    b = run(part, m, 2, 0.01, variant=1, k=k, w=w)
+    b = run(part, m, 2, 0.01, variant=1, k=k, w=w, unit=64)   # the LDS route always slices by whole 64-source tiles
     assert a.tobytes() == b.tobytes()
+    assert a.tobytes() == run(part, m, 2, 0.01, variant=0, k=k, w=w, unit=8).tobytes()   # asked for 8: still 64 there
 
 
 def test_source_count_sweep_both_routes_agree_bitwise():
@@ -344,10 +345,54 @@ def test_source_count_sweep_both_routes_agree_bitwise():
         assert m == m_want
         for knobs in (dict(k=1, w=1), dict(k=2, w=16), dict(k=2, w=4, split=3), dict(k=1, w=4, passes=2)):
             a = run(part, m, 2, 0.01, variant=0, **knobs)
-            b = run(part, m, 2, 0.01, variant=1, **knobs)
+            b = run(part, m, 2, 0.01, variant=1, unit=64, **knobs)   # same granule as the LDS route's whole tiles
             assert a.tobytes() == b.tobytes(), f"routes differ at {m_want} sources, {knobs}"
         if m_want in (1, 9, 64, 257, 1031):
             check_one_step(run(part, m, 1, 0.01, variant=1, k=1, w=1), part, m, 0.01)
+
+
+@pytest.mark.parametrize("unit", [8, 16, 32])
+def test_fine_source_granules(unit):
+    """Latency-bound launches slice the sources in granules of 8 / 16 / 32 instead of 64 (StepParams::unit): every
+    source must still be added exactly once whatever the count, the split and the waves per workgroup -- checked against
+    float64 at source counts around every granule, tile and block boundary, and against the 64-source granule."""
+    counts = [1, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 100, 127, 129, 250, 255, 256, 257, 263, 511, 520, 1000, 1031, 2049]
+    for m_want in counts:
+        n = m_want + 70
+        part, m = synth(n, 1.0, seed=1000 + m_want)
+        part[m_want:, 6] = 0.0
+        part, m = ob.partition(part)
+        assert m == m_want
+        coarse = run(part, m, 1, 0.01, k=1, w=1, unit=64)
+        for knobs in (dict(k=1, w=16), dict(k=2, w=4, split=3), dict(k=1, w=8, split=16), dict(k=2, w=16, passes=2), dict(k=1, w=1)):
+            got = run(part, m, 1, 0.01, unit=unit, **knobs)
+            acc64, mag = ob.acc_f64(part, m)
+            err = np.abs(got[:, 4:6].astype(np.float64) - acc64)
+            assert np.all(err <= acc_bound(acc64, mag)), f"{m_want} sources, unit {unit}, {knobs}: {np.max(err / acc_bound(acc64, mag)):.3f}"
+            assert np.all(np.abs(got[:, 4:6].astype(np.float64) - coarse[:, 4:6]) <= 2 * acc_bound(acc64, mag))
+            v = part[:, 2:4] + got[:, 4:6] * np.float32(0.01)
+            assert np.array_equal(got[:, 2:4], v) and np.array_equal(got[:, 0:2], part[:, 0:2] + v * np.float32(0.01))
+        # one wave walking everything in granules of `unit` adds the sources in index order: same bits as the 64 granule
+        assert run(part, m, 1, 0.01, k=1, w=1, unit=unit).tobytes() == coarse.tobytes()
+
+
+def test_auto_shape_uses_fine_granules_on_small_worlds(golden):
+    part, m = ob.partition(golden("ic_333.bin"))
+    sim = nb.SimPipeline(333, m)
+    sim.set_data(part)
+    sim.update(2, 0.01)
+    shape = sim.launch_shape()
+    got = sim.get_data()
+    sim.close()
+    assert shape["unit"] in (8, 16) and shape["w"] == 16 and shape["split"] == 1     # 150-odd sources over 16 waves
+    want = ob.step(part, m, 0.01, 2)
+    assert rel_l2_pos(got, want) <= 1e-6
+    lds = nb.SimPipeline(333, m)
+    lds.configure(variant=0)
+    lds.set_data(part)
+    lds.update(1, 0.01)
+    assert lds.launch_shape()["unit"] == 64                                             # the LDS route: whole tiles
+    lds.close()
 
 
 @pytest.mark.parametrize("P,n,frac", [(2, 700, 0.9), (3, 1500, 0.6), (8, 5000, 0.8), (5, 333, 1.0)])
