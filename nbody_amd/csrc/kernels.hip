@@ -579,6 +579,7 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
     // smaller split.  More, shorter workgroups also shrink the launch's ramp-up/ragged-end share.  K = 4 is left out: 71 VGPRs, lower
     // occupancy, never faster (profiles/r01_sweep4_shapes_by_n.txt).
     if (compute_units <= 0) compute_units = 256;
+    if (want.variant == VARIANT_LDS) want.unit = CHUNK;  // the LDS route stages whole 64-source tiles, whatever was asked
     const uint32_t chunks = (n_src + CHUNK - 1) / CHUNK;
     const bool small = ((uint64_t)n_recv + 2 * WAVE - 1) / (2 * WAVE) < (uint64_t)compute_units * 2;
     LaunchShape best = want;
@@ -598,7 +599,6 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
                 // fewer chunks than the workgroup has waves, and ties keep the coarser granule (64 first)
                 for (int unit = CHUNK; unit >= 8; unit /= 2) {
                     if (want.unit != 0 && want.unit != unit) continue;
-                    if (want.variant == VARIANT_LDS && unit != CHUNK) continue;  // the LDS route stages whole 64-source tiles
                     if (!small && want.unit == 0 && unit != CHUNK) continue;
                     double cost;
                     if (small) {
@@ -635,7 +635,6 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
         best.split = want.split ? want.split : 1;
         best.unit = want.unit ? want.unit : CHUNK;
     }
-    if (want.variant == VARIANT_LDS) best.unit = CHUNK;
     return best;
 }
 

@@ -401,7 +401,7 @@ def test_overlapped_shards_both_routes_agree_bitwise(P, n, frac):
     part, m = synth(n, frac, seed=n + P)
     outs = []
     for variant in (0, 1):
-        g = nb.LocalShardGroup(n, m, P, overlap=1, variant=variant, k=2, w=4)
+        g = nb.LocalShardGroup(n, m, P, overlap=1, variant=variant, k=2, w=4, unit=64)   # one granule for both routes
         g.set_data(part)
         g.step(2, 0.01)
         outs.append(g.get_data(P - 1))
