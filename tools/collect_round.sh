@@ -40,3 +40,7 @@ for P in 2 4; do
   python -m torch.distributed.run --nnodes=1 --nproc-per-node $P --master-addr 127.0.0.1 --master-port 2954$P bench.py --gpus $P \
       --transport host --steps 10 --warmup 2 > $O/${TAG}_rehearsal_${P}ranks_host.json 2> $O/${TAG}_rehearsal_${P}ranks_host.err; echo "host-transport P=$P rc=$?"
 done
+{
+  echo "== clock ramp-up after host-side world setup: nbody-bench --gpu --n 20000 --n 50000 with longer warm-up calls (reference: 10 steps, bench.c:21) =="
+  for w in 10 400 1600; do ./nbody_amd/lib/nbody-bench --gpu --n 20000 --n 50000 --warmup $w | tail -2 | cut -f2,3,6 | tr "\n" " "; echo " <- warm-up steps: $w"; done
+} > $O/${TAG}_warmup_ramp.txt 2>&1; echo "ramp rc=$?"
