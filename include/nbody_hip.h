@@ -199,6 +199,9 @@ void nb_hip_launch_shape(const SimPipeline *sim, int *k, int *w, int *variant, i
  */
 void nb_hip_plan_launch(uint32_t n_recv, uint32_t n_src, int compute_units, int *k, int *w, int *split, uint32_t *workgroups);
 
+/* The source-slice granule ("unit" knob: 64, 32, 16 or 8 sources) the same arithmetic picks for such a launch. */
+int nb_hip_plan_launch_unit(uint32_t n_recv, uint32_t n_src, int compute_units);
+
 /* -- sharded (multi-GPU) pipeline: one process per GPU, N/P receivers each -- */
 
 #define NB_HIP_UNIQUE_ID_BYTES 128

@@ -63,6 +63,7 @@ HIP_API = {
                                    C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "nb_hip_plan_launch": (None, [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
+    "nb_hip_plan_launch_unit": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int]),
     "nb_hip_comm_unique_id": (None, [C.c_void_p]),
     "CreateSimPipelineSharded": (C.c_void_p, [WorldData, C.c_int, C.c_int, C.c_void_p]),
     "CreateSimPipelineShardedWith": (C.c_void_p, [WorldData, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]),
@@ -154,7 +155,8 @@ def shard_plan(total_len, mass_len, rank, nranks):
 def plan_launch(n_recv, n_src, compute_units=256):
     k, w, sp, g = C.c_int(), C.c_int(), C.c_int(), C.c_uint32()
     hip_lib().nb_hip_plan_launch(n_recv, n_src, compute_units, C.byref(k), C.byref(w), C.byref(sp), C.byref(g))
-    return {"k": k.value, "w": w.value, "split": sp.value, "workgroups": g.value}
+    return {"k": k.value, "w": w.value, "split": sp.value, "workgroups": g.value,
+            "unit": int(hip_lib().nb_hip_plan_launch_unit(n_recv, n_src, compute_units))}
 
 
 def comm_unique_id():

@@ -501,6 +501,26 @@ void materialize(SimPipeline *s) {
     }
     s->on_device = true;
     pin_host(s);
+    // The first hipGraph a process instantiates and launches costs ~9 ms of runtime set-up (seen as a 146 us/step
+    // 100-step call at N = 20 000 where the next one took 54).  Pay it here, with a one-node graph captured from this
+    // pipeline's stream, instead of inside whichever step call first replays a chain.
+    static bool graph_machinery_warm = false;
+    if (!graph_machinery_warm && s->use_graph != 0) {
+        graph_machinery_warm = true;
+        hipGraph_t g = nullptr;
+        hipGraphExec_t e = nullptr;
+        if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            nb::launch_set_scalar(s->stream, s->dt_dev, 0.0f);  // dt is uploaded afresh before any step (dt_valid == false)
+            if (hipStreamEndCapture(s->stream, &g) == hipSuccess && g != nullptr &&
+                hipGraphInstantiate(&e, g, nullptr, nullptr, 0) == hipSuccess) {
+                (void)hipGraphLaunch(e, s->stream);
+                (void)hipStreamSynchronize(s->stream);
+            }
+        }
+        if (e) (void)hipGraphExecDestroy(e);
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();  // best effort: a failure here only postpones the set-up cost
+    }
 }
 
 uint32_t passes_for(const SimPipeline *s, const nb::StepParams &p);
@@ -1144,6 +1164,10 @@ void nb_hip_plan_launch(uint32_t n_recv, uint32_t n_src, int compute_units, int 
         const dim3 g = nb::step_grid(sh, n_recv);
         *workgroups = g.x * g.y;
     }
+}
+
+int nb_hip_plan_launch_unit(uint32_t n_recv, uint32_t n_src, int compute_units) {
+    return nb::choose_shape({0, 0, nb::VARIANT_SMEM, 0, 0}, n_recv, n_src, compute_units).unit;
 }
 
 int nb_hip_local_group_create(WorldData data, int nranks, SimPipeline **out) {

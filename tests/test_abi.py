@@ -186,3 +186,27 @@ def test_failures_print_file_line_func_and_abort(name, code, needle):
     assert re.search(r"\.(hip|c|cpp|h):\d+ \[\w+\]", r.stderr), r.stderr
     if needle:
         assert needle in r.stderr, r.stderr
+
+
+def test_small_launch_model_against_the_committed_shape_scan():
+    """profiles/r02_sweep_shapes_units.txt is the exhaustive (K, W, split, unit) scan the small-launch cost model was
+    fitted on (3 360 timed shapes, MI355X).  The model's pick for each scanned size must stay close to the scan's best:
+    a change to choose_shape that loses more than 6 % at any size, or 2.5 % on average, is a regression."""
+    path = os.path.join(ROOT, "profiles", "r02_sweep_shapes_units.txt")
+    rows = np.loadtxt(path)                     # N M K W split unit workgroups us_per_step
+    regrets = []
+    for n in sorted(set(rows[:, 0])):
+        sub = rows[rows[:, 0] == n]
+        m = int(sub[0, 1])
+        p = nb.plan_launch(int(n), m)
+        same = sub[(sub[:, 2] == p["k"]) & (sub[:, 3] == p["w"]) & (sub[:, 5] == p["unit"])]
+        # the scan covers splits 1-6, 8, 10, 13, 16: a pick in between is priced by its better scanned neighbour (the
+        # other one may sit past a round boundary: 990 workgroups fill one round of 1024 slots, 1100 need two)
+        scanned = sorted(set(same[:, 4]))
+        near = [max([x for x in scanned if x <= p["split"]]), min([x for x in scanned if x >= p["split"]])]
+        hit = same[np.isin(same[:, 4], near)]
+        assert 1 <= len(hit) <= 2, f"N={int(n)}: the scan has no row for the pick {p}"
+        us = hit[:, 7].min()
+        regrets.append(us / sub[:, 7].min() - 1.0)
+        assert regrets[-1] <= 0.06, f"N={int(n)}: pick {p} measured {us} us, scan's best {sub[:, 7].min()} us"
+    assert np.mean(regrets) <= 0.025, regrets
