@@ -5,8 +5,9 @@
 // staging copies) and src/lib/vulkan_ctx.c (device pick, allocator).  Differences by design:
 //   * SoA in HBM (float2 pos/vel/acc, float radius/mass, float G*m) instead of 32-byte AoS records;
 //   * ping-pong position buffers instead of a full device-to-device copy per step (sim_gpu.c:316-324);
-//   * the n-step chain is a cached hipGraph of n kernel nodes whose parameters are patched when dt or
-//     the ping-pong phase changes, instead of re-recording a command buffer per call (sim_gpu.c:262-344);
+//   * n-step chains are cached hipGraphs of kernel nodes (keyed on length and ping-pong phase) instead of a command
+//     buffer re-recorded per call (sim_gpu.c:262-344); the step size sits in device memory like the reference's
+//     uniform (sim_gpu.c:268-284), so a new dt never rebuilds a chain;
 //   * device-to-host copy only when GetSimulationData asks (the reference copies after every call,
 //     sim_gpu.c:336-341);
 //   * nothing is created on the GPU until SetSimulationData, so CPU-only worlds never touch a device.
@@ -1401,9 +1402,9 @@ int nb_hip_comm_info(const SimPipeline *s, int *nranks, int *rank, int *device, 
     return 1;
 }
 
-uint32_t nb_hip_graph_stats(const SimPipeline *s, uint32_t *patches) {
+uint32_t nb_hip_graph_stats(const SimPipeline *s, uint32_t *dt_uploads) {
     NB_ASSERT(s != nullptr, "NULL pipeline");
-    if (patches) *patches = s->dt_uploads;
+    if (dt_uploads) *dt_uploads = s->dt_uploads;
     return (uint32_t)s->graphs.size();
 }
 
