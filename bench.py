@@ -48,7 +48,7 @@ PEAK_FP32_VECTOR_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)"
 N_PARTICLES = 1 << 20
 N_CONFIG5 = 1 << 22
 DT = 0.01
-KERNEL_SOURCES = ("nbody_amd/csrc/kernels.hip", "nbody_amd/csrc/kernels.h", "nbody_amd/csrc/pipeline.hip")
+KERNEL_SOURCES = ("nbody_amd/csrc/kernels.hip", "nbody_amd/csrc/kernels.h")
 
 
 def make_workload(n, all_massive=False):
@@ -145,7 +145,8 @@ def _time_reference_packedupdate(so, part, mass_len, recv, cores):
 
 
 def kernel_sources_sha():
-    """sha256 over the sources that decide the step kernel's memory traffic (what a committed PMC figure is tied to)."""
+    """sha256 over the kernel sources; with the launch shape and the source passes per step (both decided in
+    pipeline.hip, both recorded next to the figure) it is what a committed PMC traffic figure is tied to."""
     h = hashlib.sha256()
     for rel in KERNEL_SOURCES:
         with open(os.path.join(ROOT, rel), "rb") as f:
@@ -153,9 +154,10 @@ def kernel_sources_sha():
     return h.hexdigest()
 
 
-def pmc_traffic(n):
+def pmc_traffic(n, shape=None, passes=None):
     """(HBM bytes per step-kernel launch, note): rocprofv3 PMC passes cannot run inside this process, so the figure comes
-    from the committed profile -- and only counts while the kernel sources still hash to what was profiled."""
+    from the committed profile -- and only counts while the kernel sources still hash to what was profiled and this run
+    launched the same shape with the same number of source passes."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(p):
         return None, "no committed PMC profile"
@@ -163,6 +165,11 @@ def pmc_traffic(n):
         rec = json.load(f)
     if rec.get("n") not in (None, n):
         return None, f"committed PMC profile is for N={rec.get('n')}"
+    want = rec.get("launch")
+    if want is not None and shape is not None:
+        got = dict(shape, passes=passes)
+        if any(got.get(key) != val for key, val in want.items()):
+            return None, f"stale: this run launched {got}, the PMC profile {rec.get('source')} was taken with {want}"
     if rec.get("kernel_sources_sha256") != kernel_sources_sha():
         return None, ("stale: kernel sources changed since the PMC profile " + str(rec.get("source"))
                       + " was taken (tools/profile.sh + tools/summarize_profile.py refresh it)")
@@ -427,7 +434,7 @@ def main():
         achieved_tflops = launch_interactions * FLOP_PER_INTERACTION / per_launch_s / 1e12 if per_launch_s > 0 else 0.0
         passes = max(launches // max(args.steps, 1), 1)
         traffic, traffic_note = (None, "not measured for this workload") if (args.all_massive or world > 1 or args.dry_run) \
-            else pmc_traffic(n)
+            else pmc_traffic(n, shape, passes)
         roof = {
             "bound": "valu",  # fp32 vector ALU (rsq + fma); neither HBM nor MFMA bounds this path
             "achieved": achieved_tflops,

@@ -71,12 +71,19 @@ def test_bench_traffic_figure_is_tied_to_the_kernel_sources(tmp_path, monkeypatc
     sys.path.insert(0, root)
     import bench
     rec = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
-    assert set(rec) >= {"hbm_bytes_per_launch", "kernel_sources_sha256", "n", "source"}
+    assert set(rec) >= {"hbm_bytes_per_launch", "kernel_sources_sha256", "n", "source", "launch"}
     value, note = bench.pmc_traffic(1 << 20)
     if rec["kernel_sources_sha256"] == bench.kernel_sources_sha():
         assert value == rec["hbm_bytes_per_launch"] and "from profiles/" in note
     else:
         assert value is None and note.startswith("stale")
+    # a run that launched another shape, or cut the step into another number of source passes, gets no figure either
+    launch = dict(rec["launch"])
+    passes = launch.pop("passes")
+    if rec["kernel_sources_sha256"] == bench.kernel_sources_sha():
+        assert bench.pmc_traffic(1 << 20, launch, passes)[0] == rec["hbm_bytes_per_launch"]
+    assert bench.pmc_traffic(1 << 20, dict(launch, split=launch["split"] + 1), passes)[1].startswith("stale: this run launched")
+    assert bench.pmc_traffic(1 << 20, launch, passes + 1)[0] is None
     monkeypatch.setattr(bench, "kernel_sources_sha", lambda: "0" * 64)
     value, note = bench.pmc_traffic(1 << 20)
     assert value is None and note.startswith("stale")

@@ -97,8 +97,16 @@ json.dump(summary, open(os.path.join(out_dir, f"{tag}_pmc_summary.json"), "w"), 
 if "hbm_bytes_per_launch" in summary:
     sys.path.insert(0, ROOT)
     import bench  # kernel_sources_sha(): bench.py reports the figure only while the kernel sources still hash to this
+    # ... and while it launches the shape the profiled run launched (that run's own JSON line is in stats.log)
+    launch = None
+    log = os.path.join(PROF, "stats.log")
+    if os.path.exists(log):
+        for line in open(log, errors="replace"):
+            if line.startswith("{") and '"roofline"' in line:
+                rec = json.loads(line)
+                launch = dict(rec["config"]["kernel"], passes=max(rec["roofline"]["launches"] // max(rec["steps"], 1), 1))
     json.dump({"hbm_bytes_per_launch": summary["hbm_bytes_per_launch"], "source": f"profiles/{tag}_pmc_summary.json",
-               "n": 1 << 20, "kernel_sources_sha256": bench.kernel_sources_sha(),
+               "n": 1 << 20, "kernel_sources_sha256": bench.kernel_sources_sha(), "launch": launch,
                "note": "FETCH_SIZE*1024*2 (gfx950 correction) + WRITE_SIZE*1024, mean per step_kernel launch, N=2^20; "
                        "run tools/summarize_profile.py on the same tree the profile was taken from"},
               open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
