@@ -683,6 +683,10 @@ def test_world_level_path_at_baseline_size():
     w.update_cpu(0.01, 0)
     w.update_gpu(0.01, 1)
     three = w.particles()
+    frames = []
+    for _ in range(3):              # a frame loop: from the third update -> Get pair on, the read-back is eager (32 MiB of
+        w.update_gpu(0.01, 1)       # kernel stores straight into the page-locked array inside the update's submission)
+        frames.append(w.particles())
     w.close()
     sim = nb.SimPipeline(n, m)
     sim.set_data(part)
@@ -691,9 +695,15 @@ def test_world_level_path_at_baseline_size():
     sim.set_data(want2)             # what the World's re-upload after UpdateWorld_CPU(0) amounts to
     sim.update(1, 0.01)
     want3 = sim.get_data()
+    want_frames = []
+    for _ in range(3):
+        sim.update(1, 0.01)
+        want_frames.append(sim.get_data())
     sim.close()
     assert two.tobytes() == want2.tobytes()
     assert three.tobytes() == want3.tobytes()
+    for got, want in zip(frames, want_frames):
+        assert got.tobytes() == want.tobytes()
     # and the state is the right one: spot check of the third step against float64
     idx = np.unique(np.random.default_rng(11).integers(0, n, 200)).astype(np.uint32)
     acc64, mag = ob.acc_f64_subset(two, m, idx)
