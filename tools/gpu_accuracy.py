@@ -6,16 +6,16 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import nbody_amd as nb
 import oracle_binding as ob
-for n in (4096, 65536, 262144, 1 << 20):
+for n in [int(x) for x in sys.argv[1:]] or (4096, 65536, 262144, 1 << 20):
     ic = nb.make_galaxies(n, 2, seed=11037)
     w = nb.World(ic); part = w.particles(); w.close()
     m = int((part[:, 6] > 0).sum())
     rng = np.random.default_rng(n)
-    idx = np.unique(rng.integers(0, n, 2000)).astype(np.uint32)
+    idx = (np.arange(n) if n <= 2000 else np.unique(rng.integers(0, n, 2000))).astype(np.uint32)
     acc64, mag = ob.acc_f64_subset(part, m, idx)
     avx = ob.acc_avx_subset(part, m, idx).astype(np.float64)
     e_avx = np.abs(avx - acc64)
-    for knobs in (dict(), dict(w=1, k=1), dict(variant=1)):
+    for knobs in (dict(), dict(w=1, k=1), dict(variant=0)):   # auto shape (scalar-cache route), one wave per tile, LDS route
         sim = nb.SimPipeline(n, m); sim.configure(**knobs); sim.set_data(part); sim.update(1, 0.01)
         got = sim.get_data()[idx, 4:6].astype(np.float64); shape = sim.launch_shape(); sim.close()
         e = np.abs(got - acc64)
