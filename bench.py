@@ -145,12 +145,19 @@ def _time_reference_packedupdate(so, part, mass_len, recv, cores):
 
 
 def kernel_sources_sha():
-    """sha256 over the kernel sources; with the launch shape and the source passes per step (both decided in
-    pipeline.hip, both recorded next to the figure) it is what a committed PMC traffic figure is tied to."""
+    """sha256 over the kernel sources with comments and blank space removed (editing a comment must not orphan a
+    profile); with the launch shape and the source passes per step (both decided in pipeline.hip, both recorded next
+    to the figure) it is what a committed PMC traffic figure is tied to."""
+    import re
+
     h = hashlib.sha256()
     for rel in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, rel), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, rel), "r") as f:
+            text = f.read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)     # block comments
+        text = re.sub(r"//[^\n]*", "", text)                   # line comments (no string in these files holds "//")
+        text = "\n".join(line.strip() for line in text.splitlines() if line.strip())
+        h.update(text.encode())
     return h.hexdigest()
 
 

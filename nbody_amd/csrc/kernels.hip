@@ -5,7 +5,9 @@
 //
 //   * one LANE owns K receivers (register blocking), one WAVE owns 64*K receivers and a 1/W slice of the
 //     sources, one WORKGROUP = W waves over the same 64*K receivers; the W partial sums meet in LDS in a
-//     fixed order (deterministic results), then the workgroup integrates and stores;
+//     fixed order (deterministic results), then the workgroup integrates and stores; a launch may also cut the
+//     sources into `split` parts (gridDim.y) whose sums a small finish kernel adds, and slices are whole granules
+//     of 64 sources or, for latency-bound launches on the scalar-cache route, of 32 / 16 / 8 (StepParams::unit);
 //   * sources reach the VALU wave-uniformly, 12 bytes each (x, y, G*m), by one of two routes:
 //       VARIANT_LDS   each wave stages 64-source tiles in its own LDS slab: coalesced float2/float loads
 //                     (one source per lane), ds_write_b64 + b32, then broadcast ds_read_b128 (six per 8
