@@ -172,9 +172,7 @@ __device__ __forceinline__ uint32_t source_index(const StepParams &p, uint32_t v
 }
 
 // Epilogue of one receiver: optional carried-in sum, store acc, then the reference's integrator.
-// `early` = the receiver's vel / pos_in were already fetched at kernel start (v0, q0); otherwise they are loaded here.
-__device__ __forceinline__ void finish_receiver(const StepParams &p, uint32_t logical, float sx, float sy, float dt,
-                                                bool early = false, float2 v0 = float2{0.f, 0.f}, float2 q0 = float2{0.f, 0.f}) {
+__device__ __forceinline__ void finish_receiver(const StepParams &p, uint32_t logical, float sx, float sy, float dt) {
     if (logical >= p.n_recv) return;
     const uint32_t i = receiver_slot(p, logical);
     float2 a = make_float2(sx, sy);
@@ -186,10 +184,10 @@ __device__ __forceinline__ void finish_receiver(const StepParams &p, uint32_t lo
     p.acc[i] = a;
     if (p.flags & STEP_NO_FINALIZE) return;
     // semi-implicit Euler with the reference's roundings: vel += acc*dt; pos += vel*dt
-    float2 v = early ? v0 : p.vel[i];
+    float2 v = p.vel[i];
     v.x = __fadd_rn(v.x, __fmul_rn(a.x, dt));
     v.y = __fadd_rn(v.y, __fmul_rn(a.y, dt));
-    float2 q = early ? q0 : p.pos_in[i];
+    float2 q = p.pos_in[i];
     q.x = __fadd_rn(q.x, __fmul_rn(v.x, dt));
     q.y = __fadd_rn(q.y, __fmul_rn(v.y, dt));
     p.vel[i] = v;
@@ -260,27 +258,10 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
     __shared__ __attribute__((aligned(16))) float tile[VARIANT == VARIANT_LDS ? W : 1][2][3 * CHUNK];
     __shared__ float2 partial[W > 1 ? W : 1][W > 1 ? WAVE * K : 1];
 
-    // Latency-bound launches (a few thousand particles: the whole step is a handful of dependent memory round trips)
-    // fetch what the epilogue needs -- the step size and the velocity / position of the receiver this THREAD will
-    // integrate -- together with the receivers, instead of after the force loop: one round trip less on the critical
-    // path.  Only when this launch integrates (unsplit, finalising); big launches are issue-bound and skip it.
-    // (not for tuning shapes with several receivers per finishing thread, and not on the LDS route, whose staging
-    // registers leave no room: it would spill)
-    constexpr bool EARLY_FETCH = (W == 1 || W >= K) && VARIANT == VARIANT_SMEM;
-    const bool integrates_here = EARLY_FETCH && p.split == 1 && (p.flags & STEP_NO_FINALIZE) == 0;
+    // the step size: a scalar load issued first, consumed by the epilogue.  (Fetching the integrating thread's velocity
+    // and position here as well, instead of after the force loop, measured 0.1 us per step SLOWER at N = 250 ... 1 000:
+    // profiles/r02_ab_early_fetch.txt.)
     const float dt = *p.dt;
-    float2 early_v[W == 1 ? K : 1], early_q[W == 1 ? K : 1];
-#pragma unroll
-    for (int k = 0; k < (W == 1 ? K : 1); k++) {
-        early_v[k] = early_q[k] = float2{0.f, 0.f};
-        // W == 1: lane finishes its own K receivers; W > 1: thread tid finishes receiver recv_base + tid (tid < 64 K)
-        const uint32_t logical = W == 1 ? recv_base + k * WAVE + lane : recv_base + tid;
-        if (integrates_here && (W == 1 || tid < WAVE * K) && logical < p.n_recv) {
-            const uint32_t i = receiver_slot(p, logical);
-            early_v[k] = p.vel[i];
-            early_q[k] = p.pos_in[i];
-        }
-    }
 
     Receivers<K> R;
 #pragma unroll
@@ -412,17 +393,17 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
     }
 
     // ---- combine the W slices in wave order, integrate, store -------------------------------------------
-    auto finish = [&](uint32_t logical, float sx, float sy, int k) {
+    auto finish = [&](uint32_t logical, float sx, float sy) {
         if (p.split > 1) {
             if (logical < p.n_recv) p.parts[(size_t)blockIdx.y * p.n_recv + logical] = make_float2(sx, sy);
         } else {
-            finish_receiver(p, logical, sx, sy, dt, integrates_here, early_v[k], early_q[k]);
+            finish_receiver(p, logical, sx, sy, dt);
         }
     };
 
     if constexpr (W == 1) {
 #pragma unroll
-        for (int k = 0; k < K; k++) finish(recv_base + k * WAVE + lane, R.s[k].x, R.s[k].y, k);
+        for (int k = 0; k < K; k++) finish(recv_base + k * WAVE + lane, R.s[k].x, R.s[k].y);
     } else {
 #pragma unroll
         for (int k = 0; k < K; k++) partial[wid][k * WAVE + lane] = make_float2(R.s[k].x, R.s[k].y);
@@ -436,8 +417,7 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
                 sx = __fadd_rn(sx, t.x);
                 sy = __fadd_rn(sy, t.y);
             }
-            // one receiver per thread (slot == tid) whenever the early fetch is on
-            finish(recv_base + slot, sx, sy, 0);
+            finish(recv_base + slot, sx, sy);
         }
     }
 }
