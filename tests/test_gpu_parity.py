@@ -524,6 +524,30 @@ def test_random_small_worlds(seed):
     check_one_step(got, part, m, dt)
 
 
+@pytest.mark.parametrize("block", range(4))
+def test_random_worlds_random_knobs(block):
+    """Seeded fuzz over world sizes, massive fractions and every launch knob (receivers per lane, waves per workgroup,
+    source split, slice granule, source passes, source route, graph policy): one step must sit within the float64
+    tolerance with an exact integrator, and a three-step chain must give the same bytes as plain launches."""
+    rng = np.random.default_rng(9000 + block)
+    for case in range(12):
+        n = int(rng.choice([1, 2, 63, 64, 65, 127, 300, 777, 1024, 1500, 2111, 3000]))
+        frac = float(rng.choice([0.02, 0.3, 0.5, 1.0]))
+        part, m = synth(n, frac, seed=int(rng.integers(1 << 30)), extent=float(rng.choice([1e2, 1e4, 1e6])))
+        knobs = dict(k=int(rng.choice([0, 1, 2])), w=int(rng.choice([0, 1, 4, 8, 16])), split=int(rng.integers(0, 17)),
+                     unit=int(rng.choice([0, 8, 16, 32, 64])), passes=int(rng.choice([0, 1, 2, 3])),
+                     variant=int(rng.choice([0, 1])))
+        dt = float(rng.choice([0.01, 0.005, 0.02]))
+        one = run(part, m, 1, dt, **knobs)
+        acc64, mag = ob.acc_f64(part, m)
+        err = np.abs(one[:, 4:6].astype(np.float64) - acc64)
+        assert np.all(err <= acc_bound(acc64, mag)), f"case {block}.{case}: n={n} m={m} {knobs}: {np.max(err / acc_bound(acc64, mag)):.3f}"
+        v = part[:, 2:4] + one[:, 4:6] * np.float32(dt)
+        assert np.array_equal(one[:, 2:4], v) and np.array_equal(one[:, 0:2], part[:, 0:2] + v * np.float32(dt)), (n, knobs)
+        assert np.array_equal(one[:, 6:8], part[:, 6:8])
+        assert run(part, m, 3, dt, graph=1, **knobs).tobytes() == run(part, m, 3, dt, graph=0, **knobs).tobytes(), (n, knobs)
+
+
 def test_negative_mass_is_massless():
     a = np.zeros((3, 8), dtype=np.float32)
     a[:, 7] = 1.0
