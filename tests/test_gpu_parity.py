@@ -291,6 +291,23 @@ def test_dt_change_patches_the_cached_chain(golden, graph):
     assert got.tobytes() == want.tobytes()
 
 
+def test_long_runs_replay_the_canonical_chain_exactly(golden):
+    """5 000 steps in auto mode (the prebuilt 32-step chain replayed 156 times + 8 plain launches) = 50 calls of 100
+    steps = 5 000 plain launches, bit for bit; the pipeline keeps one cached chain throughout."""
+    part, m = ob.partition(golden("ic_1024.bin"))
+    want = run(part, m, 5000, 0.001, graph=0)
+    assert run(part, m, 5000, 0.001).tobytes() == want.tobytes()
+    sim = nb.SimPipeline(1024, m)
+    sim.set_data(part)
+    for _ in range(50):
+        sim.update(100, 0.001)
+    stats = sim.graph_stats()
+    got = sim.get_data()
+    sim.close()
+    assert got.tobytes() == want.tobytes() and stats == {"cached": 1, "dt_uploads": 1}
+    assert np.all(np.isfinite(got))
+
+
 def test_set_data_again_restarts_from_the_new_state(golden):
     part, m = ob.partition(golden("ic_333.bin"))
     sim = nb.SimPipeline(333, m)
