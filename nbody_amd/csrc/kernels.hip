@@ -14,8 +14,8 @@
 //                     sources); double-buffered, no workgroup barrier in the loop;
 //       VARIANT_SMEM  the wave reads its slice through the scalar cache (s_load_dwordx8/x16) so sources
 //                     arrive in SGPRs and feed the VALU as scalar operands; no LDS, no VGPR staging;
-//   * per interaction: v_pk_add (dx,dy), 2 fma (dist^2 + receiver radius), v_rsq_f32, 3 mul, v_pk_fma into the
-//     accumulator pair = 8 VALU instructions (10 scalar-equivalent) against the reference's 14 counted flops
+//   * per interaction: 2 sub (dx, dy), 2 fma (dist^2 + receiver radius), v_rsq_f32, 3 mul, 2 fma into the
+//     accumulators = 10 plain VALU instructions, none packed, against the reference's 14 counted flops
 //     (SURVEY.md 8d keeps 14 as the roofline convention);
 //   * sums are two-level (plain over blocks of 256 sources, then Kahan over the block totals), so the fp32 result
 //     stays within ~4e-7 * sum|contribution| (rms) of the float64 sum at any N and launch shape, 180x closer than
@@ -78,46 +78,56 @@ struct Receivers {
 
 // One source against the K receivers of this lane.  sxy/sg are wave-uniform (SGPRs).
 //
-// The eight VALU instructions of an interaction are written out as one asm statement per (source, receiver):
-//     v_pk_add_f32  d   = (sx, sy) - (x, y)
-//     v_fma_f32     q   = d.x * d.x + radius         softening: + radius of the RECEIVER, not squared
-//     v_fmac_f32    q  += d.y * d.y
-//     v_rsq_f32     q   = 1 / sqrt(q)                1 ulp; issued at raised wave priority
-//     v_mul_f32     t   = q * q
-//     v_mul_f32     u   = (G*m) * q                  G*m straight from its SGPR
-//     v_mul_f32     u   = u * t                      G*m / dist^3
-//     v_pk_fma_f32  acc += d * (u, u)                op_sel_hi broadcasts u
+// The ten VALU instructions of an interaction are written out as one asm statement per (source, receiver):
+//     v_sub_f32   dx  = sx - x
+//     v_sub_f32   dy  = sy - y
+//     v_fma_f32   q   = dx * dx + radius           softening: + radius of the RECEIVER, not squared
+//     v_fmac_f32  q  += dy * dy
+//     v_rsq_f32   q   = 1 / sqrt(q)                1 ulp; issued at raised wave priority
+//     v_mul_f32   u   = (G*m) * q                  G*m straight from its SGPR
+//     v_mul_f32   t   = q * q
+//     v_mul_f32   u   = u * t                      G*m / dist^3
+//     v_fmac_f32  ax += dx * u
+//     v_fmac_f32  ay += dy * u
+// = 9 plain instructions (2 issue cycles each) + one quarter-rate transcendental (8) = 26 cycles per wave-interaction,
+// the floor of this mix; the kernel runs at 27.2 (profiles/r02_ab_plain_body.txt).
+// No packed instruction: round 1 shipped v_pk_add_f32 for (dx, dy) and v_pk_fma_f32 for the accumulation -- two fewer
+// instructions, the same nominal cycles -- and measured 28.4-28.9 cycles; the all-plain body is 4.5 % faster on every
+// box tried (51.2 -> 48.8 ms per launch at N = 2^20), while unpacking only one of the two is slower than either
+// (+1 % and +12 %): packed f32 costs more than its two halves when it sits between plain and transcendental
+// instructions (MI355X_MICROARCH.md notes the same beside MFMAs).
 // Why asm: (1) left to hipcc, the multiplies become two v_pk_mul_f32 plus a v_mov, and both the schedule and
 // the register count of the unrolled loop swing with unrelated edits (55..75 VGPRs; 65 halves the occupancy of a
 // 1024-thread workgroup): the same loop measured anywhere from 105 to 151 ms per step at N = 2^20
-// (profiles/r01_sweep_auto_split.txt, r01_sweep8_full_asm_nops_alignment.txt).  One fixed sequence on six fixed
-// temporaries cannot drift: 36 VGPRs, 108-110 ms.  (2) A v_rsq_f32 that lands between other waves' plain VALU
+// (profiles/r01_sweep_auto_split.txt, r01_sweep8_full_asm_nops_alignment.txt).  One fixed sequence on five fixed
+// temporaries cannot drift.  (2) A v_rsq_f32 that lands between other waves' plain VALU
 // instructions costs ~16 cycles instead of 8 on gfx950; raising the wave priority for just that instruction buys
-// 6 % here (profiles/r01_ubench5_setprio_rsq.txt, r01_sweep9_nops_and_static_priority.txt; static per-wave
-// priorities instead are 3x SLOWER).  (3) gfx950 needs one wait state between a transcendental and the VALU
-// instruction that reads its result, and hipcc cannot pad inside asm: the s_setprio 0 that follows the rsq IS that
-// wait state (an earlier version with nothing in between read stale values; the parity tests caught it).  An
-// extra s_nop there costs 2.3 %.  The other dependent pairs are ordinary VALU read-after-write, which the
-// hardware interlocks.  (4) One statement per interaction, not one per 8 sources: hipcc pads each asm boundary with
-// an s_nop, which makes the body 52 + 4 = 56 bytes; the same 52-byte body back to back with no filler at all runs
-// 8 % slower (instruction-stream phase), see the second table of r01_sweep9.  Each interaction is a serial
-// dependency chain on purpose: with 8 waves per SIMD the other waves fill the gaps, and interleaved or
-// software-pipelined orders measured slower (profiles/r01_ubench3_hand_scheduled_bodies.txt).
-// The statement is pure (no memory, not volatile); 10 instructions, 52 bytes.  The same instructions in their
-// 8-byte VOP3 encodings (72 bytes) run 11.6 % slower, so the short encodings the assembler picks matter.
-// Temporaries (clobbered): d = v[30:31], t = v32, q = v33, u = v[36:37].  Ten other assignments measured the
-// same within the 1-2 % box-to-box spread.
-#define NB_INTERACTION_ASM                                                      \
-    "v_pk_add_f32 v[30:31], %[s], %[p] neg_lo:[0,1] neg_hi:[0,1]\n\t"          \
-    "v_fma_f32 v33, v30, v30, %[r]\n\t"                                        \
-    "v_fmac_f32 v33, v31, v31\n\t"                                             \
-    "s_setprio 3\n\t"                                                          \
-    "v_rsq_f32 v33, v33\n\t"                                                   \
-    "s_setprio 0\n\t"                                                          \
-    "v_mul_f32 v32, v33, v33\n\t"                                              \
-    "v_mul_f32 v36, %[g], v33\n\t"                                             \
-    "v_mul_f32 v36, v36, v32\n\t"                                              \
-    "v_pk_fma_f32 %[a], v[30:31], v[36:37], %[a] op_sel_hi:[1,0,1]"
+// 6 % with the packed body and 13 % with this one (profiles/r01_ubench5_setprio_rsq.txt,
+// r01_sweep9_nops_and_static_priority.txt, r02_ab_plain_body.txt; static per-wave priorities instead are 3x SLOWER;
+// priority 1 instead of 3, or the window opened one instruction earlier: within 0.3 %).  (3) gfx950 needs one wait
+// state between a transcendental and the VALU instruction that reads its result, and hipcc cannot pad inside asm:
+// the s_setprio 0 that follows the rsq IS that wait state (an earlier version with nothing in between read stale
+// values; the parity tests caught it, and tests/test_isa.py now checks the ISA).  The other dependent pairs are
+// ordinary VALU read-after-write, which the hardware interlocks.  (4) One statement per interaction: hipcc pads each
+// asm boundary with an s_nop (56 + 4 bytes).  Each interaction is a serial dependency chain on purpose: with 8 waves per
+// SIMD the other waves fill the gaps, and interleaved or software-pipelined orders measured slower
+// (profiles/r01_ubench3_hand_scheduled_bodies.txt).
+// The statement is pure (no memory, not volatile); 12 instructions, 56 bytes, all in their short encodings.
+// Temporaries (clobbered): dx = v30, dy = v31, t = v32, q = v33, u = v36 (v37 stays on the list: generated tuning
+// bodies use it).
+#define NB_INTERACTION_ASM                                  \
+    "v_sub_f32 v30, %[sx], %[px]\n\t"                       \
+    "v_sub_f32 v31, %[sy], %[py]\n\t"                       \
+    "v_fma_f32 v33, v30, v30, %[r]\n\t"                     \
+    "v_fmac_f32 v33, v31, v31\n\t"                          \
+    "s_setprio 3\n\t"                                       \
+    "v_rsq_f32 v33, v33\n\t"                                \
+    "s_setprio 0\n\t"                                       \
+    "v_mul_f32 v36, %[g], v33\n\t"                          \
+    "v_mul_f32 v32, v33, v33\n\t"                           \
+    "v_mul_f32 v36, v36, v32\n\t"                           \
+    "v_fmac_f32 %[ax], v30, v36\n\t"                        \
+    "v_fmac_f32 %[ay], v31, v36"
 #define NB_CLOBBERS "v30", "v31", "v32", "v33", "v36", "v37"
 
 // SRC_IN_SGPR: the source sits in SGPRs (scalar-cache route) or in VGPRs holding a wave-uniform value
@@ -128,13 +138,13 @@ __device__ __forceinline__ void interact(Receivers<K> &R, f2v sxy, float sg) {
     for (int k = 0; k < K; k++) {
         if constexpr (SRC_IN_SGPR) {
             asm(NB_INTERACTION_ASM
-                : [a] "+v"(R.a[k])
-                : [s] "s"(sxy), [g] "s"(sg), [p] "v"(R.p[k]), [r] "v"(R.r[k])
+                : [ax] "+v"(R.a[k].x), [ay] "+v"(R.a[k].y)
+                : [sx] "s"(sxy.x), [sy] "s"(sxy.y), [g] "s"(sg), [px] "v"(R.p[k].x), [py] "v"(R.p[k].y), [r] "v"(R.r[k])
                 : NB_CLOBBERS);
         } else {
             asm(NB_INTERACTION_ASM
-                : [a] "+v"(R.a[k])
-                : [s] "v"(sxy), [g] "v"(sg), [p] "v"(R.p[k]), [r] "v"(R.r[k])
+                : [ax] "+v"(R.a[k].x), [ay] "+v"(R.a[k].y)
+                : [sx] "v"(sxy.x), [sy] "v"(sxy.y), [g] "v"(sg), [px] "v"(R.p[k].x), [py] "v"(R.p[k].y), [r] "v"(R.r[k])
                 : NB_CLOBBERS);
         }
     }

@@ -97,13 +97,19 @@ def test_step_kernels_fit_the_occupancy_the_launch_bounds_promise(isa):
     assert smem and max(smem) <= 48, smem
 
 
-def test_interaction_body_is_the_ten_instruction_sequence(isa):
-    """One (source, receiver) interaction = v_pk_add, v_fma, v_fmac, s_setprio, v_rsq, s_setprio, 3 x v_mul, v_pk_fma
-    in their short encodings (the 8-byte VOP3 forms measured 11.6 % slower: DESIGN.md section 3)."""
+def test_interaction_body_is_the_twelve_instruction_sequence(isa):
+    """One (source, receiver) interaction = 2 x v_sub, v_fma, v_fmac, s_setprio, v_rsq, s_setprio, 3 x v_mul, 2 x v_fmac
+    in their short encodings (the 8-byte VOP3 forms measured 11.6 % slower), and NO packed f32 instruction in the
+    step kernels' loops (v_pk_add / v_pk_fma around the transcendental cost 4.5 %: DESIGN.md section 3)."""
     body = next(b for n, b in functions(isa).items() if "step_kernelILi2ELi16ELi1E" in n)
-    want = ["v_pk_add_f32", "v_fma_f32", "v_fmac_f32", "s_setprio", "v_rsq_f32", "s_setprio", "v_mul_f32", "v_mul_f32",
-            "v_mul_f32", "v_pk_fma_f32"]
+    want = ["v_sub_f32", "v_sub_f32", "v_fma_f32", "v_fmac_f32", "s_setprio", "v_rsq_f32", "s_setprio", "v_mul_f32",
+            "v_mul_f32", "v_mul_f32", "v_fmac_f32", "v_fmac_f32"]
     ops = [ins.split()[0] for ins in body]
     hits = sum(1 for i in range(len(ops) - len(want) + 1) if ops[i:i + len(want)] == want)
     assert hits >= 32, hits      # two unrolled 8-source groups x 2 receivers per lane, at least
-    assert not any(op.endswith("_e64") for op in ops if op.startswith(("v_mul_f32", "v_fmac_f32", "v_rsq_f32")))
+    assert not any(op.endswith("_e64") for op in ops if op.startswith(("v_mul_f32", "v_fmac_f32", "v_rsq_f32", "v_sub_f32")))
+    # between one v_rsq_f32 and the next (one interaction's tail, the next one's head) nothing packed may appear
+    rsq = [i for i, op in enumerate(ops) if op == "v_rsq_f32"]
+    for a, b in zip(rsq, rsq[1:]):
+        if b - a <= 14:
+            assert not any(op.startswith("v_pk_") for op in ops[a:b]), ops[a:b]

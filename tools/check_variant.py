@@ -12,7 +12,7 @@ bound = 1e-4 * np.abs(acc64) + 1e-6 * mag
 bad = 0
 ref = None
 for variant in (0, 1):
-    for (k, w) in ((1, 1), (1, 16), (2, 4), (2, 16), (4, 1), (4, 8), (4, 16)):
+    for (k, w) in ((1, 1), (1, 16), (2, 4), (2, 16), (2, 1), (1, 8)):
         sim = nb.SimPipeline(4096, m); sim.configure(variant=variant, k=k, w=w); sim.set_data(part); sim.update(1, 0.01)
         got = sim.get_data(); sim.close()
         ratio = float(np.max(np.abs(got[:, 4:6] - acc64) / bound))

@@ -39,8 +39,8 @@ for key in sorted(agg, key=lambda k: (k[1], k[0])):
                          f"parked on s_waitcnt/barrier (SQ_WAIT_ANY) {c.get('SQ_WAIT_ANY', 0) / c['SQ_WAVE_CYCLES']:.2f}")
     if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
         simd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024
-        lines.append(f"    -> VALU issue utilisation over the kernel's active time (SQ_INSTS_VALU * 26/8 / SIMD-cycles): "
-                     f"{c['SQ_INSTS_VALU'] * 26 / 8 / simd_cycles:.2f}")
+        lines.append(f"    -> VALU issue utilisation over the kernel's active time (SQ_INSTS_VALU * 26/10 / SIMD-cycles): "
+                     f"{c['SQ_INSTS_VALU'] * 26 / 10 / simd_cycles:.2f}")
 stats = glob.glob(os.path.join(PROF, "stats", "*", "*_kernel_stats.csv"))
 if stats:
     lines.append("")

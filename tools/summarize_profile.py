@@ -81,11 +81,11 @@ if "SQ_ACTIVE_INST_VALU" in mean and "GRBM_GUI_ACTIVE" in mean:
     lines.append(f"VALU busy = 4 * SQ_ACTIVE_INST_VALU / (SIMDs * cycles) = {busy:.3f}   (> 1: the counter adds up every wave's "
                  f"in-flight time, and several waves' instructions overlap in the pipe)")
     if "SQ_INSTS_VALU" in mean:
-        # the step kernel's mix per interaction: 2 packed (4 cycles) + 5 plain (2 cycles) + 1 v_rsq_f32 (8 cycles)
-        # = 26 issue cycles per 8 instructions (profiles/r01_ubench4_true_cycles.txt)
-        issue = mean["SQ_INSTS_VALU"] * (26.0 / 8.0) / simd_cycles
+        # the step kernel's mix per interaction: 9 plain (2 cycles) + 1 v_rsq_f32 (8 cycles)
+        # = 26 issue cycles per 10 instructions (profiles/r01_ubench4_true_cycles.txt; round 1's packed body: 26 per 8)
+        issue = mean["SQ_INSTS_VALU"] * (26.0 / 10.0) / simd_cycles
         summary["valu_issue_utilisation"] = issue
-        lines.append(f"VALU issue utilisation = SQ_INSTS_VALU * (26/8 cycles per instruction of this mix) / (SIMDs * cycles) = {issue:.3f}")
+        lines.append(f"VALU issue utilisation = SQ_INSTS_VALU * (26/10 cycles per instruction of this mix) / (SIMDs * cycles) = {issue:.3f}")
 if "TCC_HIT_sum" in mean:
     hr = mean["TCC_HIT_sum"] / (mean["TCC_HIT_sum"] + mean["TCC_MISS_sum"])
     summary["l2_hit_rate"] = hr
