@@ -19,8 +19,8 @@
  *                  reference's single timed call; a row of a few hundred microseconds is at the mercy of one OS hiccup)
  * and more columns: interactions/s = N * mass_len * steps / time per backend, and for the GPU the share of the
  * fp32 roofline that is (14 flop per interaction, 157.3 TFLOP/s), then what the chip allows at THIS size:
- *   GPU floor = N * mass_len / 5.3e12 interactions/s  (the rate the step kernel sustains at N = 2^20, i.e. the
- *               instruction-mix bound of its 8 VALU instructions per interaction)
+ *   GPU floor = N * mass_len / 5.7e12 interactions/s  (the rate the step kernel sustains at N = 2^20, i.e. the
+ *               instruction-mix bound of its 10 VALU instructions per interaction)
  *             + kernels per step x 1.7 us              (dependent-launch floor inside a hipGraph on this box,
  *               profiles/r01_ubench6_launch_floor.txt; a step is 1 kernel, or 2 when the sources are split)
  *   %floor    = floor / measured: how close the step is to that bound.  Below N ~ 50 000 a launch cannot fill the
@@ -38,7 +38,7 @@
 #include <nbody.h>
 #include <nbody_hip.h>
 
-#define LARGE_N_RATE 5.3e12       /* interactions/s of the step kernel at N = 2^20 (bench.py, BENCH_r01.json) */
+#define LARGE_N_RATE 5.7e12       /* interactions/s of the step kernel at N = 2^20 (bench.py, profiles/r02_bench.json) */
 #define LAUNCH_FLOOR_US 1.7       /* per dependent kernel inside a hipGraph (profiles/r01_ubench6_launch_floor.txt) */
 
 typedef void (*UpdateFn)(World *, float, uint32_t);
