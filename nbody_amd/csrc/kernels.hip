@@ -192,17 +192,17 @@ __device__ __forceinline__ void interact(Receivers<K> &R, f2v sxy, float sg) {
 // 8 sources (x,y interleaved in P, G*m in G) against the K receivers: 8*K interaction statements, source-major.
 template <int K, bool SRC_IN_SGPR, typename VP, typename VG>
 __device__ __forceinline__ void interact8(Receivers<K> &R, const VP &P, const VG &G) {
-#ifdef NB_GEN_BODY
-    // tuning builds only (tools/gen_body.py): the 16 interactions as one generated statement
+#ifdef NB_EXPGEN_ASM  // tuning builds only (tools/gen_plain_body.py): NB_EXPGEN_S sources x 2 receivers per generated statement
     if constexpr (K == 2 && SRC_IN_SGPR) {
-        asm(NB_GEN8_ASM
-            : [a0] "+v"(R.a[0]), [a1] "+v"(R.a[1])
-            : [s0] "s"(f2v{P[0], P[1]}), [s1] "s"(f2v{P[2], P[3]}), [s2] "s"(f2v{P[4], P[5]}),
-              [s3] "s"(f2v{P[6], P[7]}), [s4] "s"(f2v{P[8], P[9]}), [s5] "s"(f2v{P[10], P[11]}),
-              [s6] "s"(f2v{P[12], P[13]}), [s7] "s"(f2v{P[14], P[15]}), [g0] "s"(G[0]), [g1] "s"(G[1]),
-              [g2] "s"(G[2]), [g3] "s"(G[3]), [g4] "s"(G[4]), [g5] "s"(G[5]), [g6] "s"(G[6]), [g7] "s"(G[7]),
-              [p0] "v"(R.p[0]), [p1] "v"(R.p[1]), [r0] "v"(R.r[0]), [r1] "v"(R.r[1])
-            : "v30", "v31", "v32", "v33", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43");
+#pragma unroll
+        for (int u = 0; u < 8; u += NB_EXPGEN_S) {
+            asm(NB_EXPGEN_ASM
+                : [ax0] "+v"(R.a[0].x), [ay0] "+v"(R.a[0].y), [ax1] "+v"(R.a[1].x), [ay1] "+v"(R.a[1].y)
+                : [sx0] "s"(P[2 * u]), [sy0] "s"(P[2 * u + 1]), [g0] "s"(G[u]),
+                  [sx1] "s"(P[2 * ((u + 1) & 7)]), [sy1] "s"(P[2 * ((u + 1) & 7) + 1]), [g1] "s"(G[(u + 1) & 7]),
+                  [px0] "v"(R.p[0].x), [py0] "v"(R.p[0].y), [r0] "v"(R.r[0]), [px1] "v"(R.p[1].x), [py1] "v"(R.p[1].y), [r1] "v"(R.r[1])
+                : NB_EXPGEN_CLOBBERS);
+        }
         return;
     }
 #endif
