@@ -38,6 +38,7 @@ constexpr int CLOSE_EVERY = 4;  // tiles per summation block: plain sums over 25
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v8f __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 typedef float f2v __attribute__((ext_vector_type(2)));
 
@@ -165,12 +166,20 @@ struct Receivers {
 // (LDS broadcast reads); the instructions are the same, only the operand class differs.
 template <int K, bool SRC_IN_SGPR>
 __device__ __forceinline__ void interact(Receivers<K> &R, f2v sxy, float sg) {
-    if constexpr (K == 2 && SRC_IN_SGPR) {  // (the LDS route has no three VGPRs to spare: it keeps two single statements)
-        asm(NB_INTERACTION2_ASM
-            : [ax0] "+v"(R.a[0].x), [ay0] "+v"(R.a[0].y), [ax1] "+v"(R.a[1].x), [ay1] "+v"(R.a[1].y)
-            : [sx] "s"(sxy.x), [sy] "s"(sxy.y), [g] "s"(sg), [px0] "v"(R.p[0].x), [py0] "v"(R.p[0].y), [r0] "v"(R.r[0]),
-              [px1] "v"(R.p[1].x), [py1] "v"(R.p[1].y), [r1] "v"(R.r[1])
-            : NB_CLOBBERS2);
+    if constexpr (K == 2) {
+        if constexpr (SRC_IN_SGPR) {
+            asm(NB_INTERACTION2_ASM
+                : [ax0] "+v"(R.a[0].x), [ay0] "+v"(R.a[0].y), [ax1] "+v"(R.a[1].x), [ay1] "+v"(R.a[1].y)
+                : [sx] "s"(sxy.x), [sy] "s"(sxy.y), [g] "s"(sg), [px0] "v"(R.p[0].x), [py0] "v"(R.p[0].y), [r0] "v"(R.r[0]),
+                  [px1] "v"(R.p[1].x), [py1] "v"(R.p[1].y), [r1] "v"(R.r[1])
+                : NB_CLOBBERS2);
+        } else {
+            asm(NB_INTERACTION2_ASM
+                : [ax0] "+v"(R.a[0].x), [ay0] "+v"(R.a[0].y), [ax1] "+v"(R.a[1].x), [ay1] "+v"(R.a[1].y)
+                : [sx] "v"(sxy.x), [sy] "v"(sxy.y), [g] "v"(sg), [px0] "v"(R.p[0].x), [py0] "v"(R.p[0].y), [r0] "v"(R.r[0]),
+                  [px1] "v"(R.p[1].x), [py1] "v"(R.p[1].y), [r1] "v"(R.r[1])
+                : NB_CLOBBERS2);
+        }
         return;
     }
 #pragma unroll
@@ -365,11 +374,14 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int jj = 0; jj < CHUNK; jj += 8) {
-                // broadcast ds_read_b128: every lane reads the same 16 bytes; (x, y) pairs land in aligned VGPR pairs
-                const v16f P = *reinterpret_cast<const v16f *>(&T[buf][2 * jj]);
-                const v8f G = *reinterpret_cast<const v8f *>(&T[buf][2 * CHUNK + jj]);
-                interact8<K, false>(R, P, G);
+            for (int jj = 0; jj < CHUNK; jj += 4) {
+                // broadcast ds_read_b128: every lane reads the same 16 bytes.  Four sources per read group (two reads
+                // of positions, one of G*m): 12 staging VGPRs instead of 24, which is what leaves room for the
+                // paired-rsq body with two receivers per lane
+                const v8f P = *reinterpret_cast<const v8f *>(&T[buf][2 * jj]);
+                const v4f G = *reinterpret_cast<const v4f *>(&T[buf][2 * CHUNK + jj]);
+#pragma unroll
+                for (int u = 0; u < 4; u++) interact<K, false>(R, f2v{P[2 * u], P[2 * u + 1]}, G[u]);
             }
             if (((c - c_lo) & (CLOSE_EVERY - 1)) == CLOSE_EVERY - 1) R.close_chunk();
             buf ^= 1;
