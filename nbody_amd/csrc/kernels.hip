@@ -659,7 +659,9 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
                         cost = ((double)rounds + TAIL) * ((double)k * (wave_chunks ? wave_chunks : 1) + 1.0);
                         if (sp > 1) cost += 3.0 + 0.02 * sp;
                         if (w < 16) cost *= 1.01;
-                        if (k == 1) cost *= 1.25;  // measured: K = 1 is slower per interaction at large N
+                        // K = 1 per interaction at large N: 1.6 % slower than K = 2 with the plain body (48.6 vs 47.8 ms
+                        // per launch at N = 2^20; it was 25 % with the packed body, whose single statement ran alone)
+                        if (k == 1) cost *= 1.02;
                     }
                     if (best_cost < 0.0 || cost < best_cost * 0.999) {
                         best_cost = cost;

@@ -124,11 +124,15 @@ def test_shard_plan_bench_case_lands_on_round_boundaries():
 
 def test_launch_plan_round_boundaries_and_splits():
     # 256 CUs, two 1024-thread workgroups resident per CU = 512 slots per round
-    for n, m in ((1 << 20, 523884), (262144, 130916), (65536, 32641), (131072, 262144)):
+    for n, m in ((1 << 20, 523884), (262144, 130916), (131072, 262144)):
         p = nb.plan_launch(n, m)
         # large grids: K = 2, W = 16, whole rounds; a modest split keeps the launch's ragged end small
         assert (p["k"], p["w"]) == (2, 16) and 1 <= p["split"] <= 8
         assert p["workgroups"] == n // 128 * p["split"] and p["workgroups"] % 512 == 0
+    # config 2 (N = 65 536): exactly two rounds of 1024-thread workgroups either way; with the plain interaction body one
+    # receiver per lane costs 1.6 % more than two, so the single-kernel unsplit shape wins (395 vs 394 us measured)
+    p = nb.plan_launch(65536, 32641)
+    assert p["w"] == 16 and p["workgroups"] == 1024 and (p["k"], p["split"]) in ((1, 1), (2, 2))
     for n, m in ((100000, 49944), (200000, 99899)):
         p = nb.plan_launch(n, m)
         assert p["split"] > 1 and p["workgroups"] == -(-n // (64 * p["k"])) * p["split"]    # off a boundary: split
