@@ -574,7 +574,7 @@ const void *pick(int k, int w) {
 
 // Launches that do not even fill the chip once with K = 2 / W = 16 workgroups (fewer than 65 536 receivers on 256
 // CUs) are priced in microseconds by a model fitted to exhaustive (K, W, split, unit) scans at N = 250 ... 50 000
-// (tools/sweep_shapes.py; profiles/r02_sweep_shapes_units.txt holds the scan, 3 360 timed shapes).  There a wave is
+// (tools/sweep_shapes.py; profiles/r02_sweep_shapes_units.txt holds the latest scan, 3 360 timed shapes).  There a wave is
 // latency-bound, not issue-bound: alone on its SIMD it needs LAT us per 64-source chunk and receiver set (a serial
 // dependency chain), and only beyond ~2 waves per SIMD does the chunk time grow with occupancy -- at THR us per wave,
 // worse (factor A) the emptier the SIMD, and worse again for K = 1 (K1A).  Every wave also costs UFIX chunks of fixed
@@ -637,7 +637,10 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
                 // (16 waves per tile beat 8 there: 4.2 vs 4.6 us at N = 800); beyond that 256- and 512-thread
                 // workgroups pack better, and the model overrates W = 16
                 const bool few_unsplit_tiles = sp == 1 && ((uint64_t)n_recv + WAVE * k - 1) / (WAVE * k) <= 24;
-                if (small && want.w == 0 && (w == 16) != few_unsplit_tiles) continue;
+                // ... with at least ~16 sources for every wave: 8 waves when there are no more than 128 sources
+                // (N = 250: 2.9 us with 8 waves of 16 sources, 3.2 with 16 waves of 8)
+                const int tiny_w = n_src <= 128 ? 8 : 16;
+                if (small && want.w == 0 && (few_unsplit_tiles ? w != tiny_w : w == 16)) continue;
                 // slice granule: 64 unless the launch is latency-bound; a finer one only has to win where a part holds
                 // fewer chunks than the workgroup has waves, and ties keep the coarser granule (64 first)
                 for (int unit = CHUNK; unit >= 8; unit /= 2) {

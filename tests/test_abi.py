@@ -140,7 +140,8 @@ def test_launch_plan_round_boundaries_and_splits():
         assert p["workgroups"] / (rounds * 256 * 32 // p["w"]) > 0.9                          # last round nearly full
     for n, m in ((250, 119), (500, 244), (800, 386)):
         p = nb.plan_launch(n, m)
-        assert (p["k"], p["w"], p["split"]) == (1, 16, 1)      # a handful of tiles: 16 waves on each, unsplit (finer granules)
+        # a handful of tiles: unsplit, 16 waves on each -- 8 while there are no more than 128 sources -- and fine granules
+        assert (p["k"], p["w"], p["split"]) == (1, 8 if m <= 128 else 16, 1) and p["unit"] < 64
     assert nb.plan_launch(20000, 9956)["split"] > 1                                         # unsplit: 69 us, split: 45 us
     for n, m in ((2000, 967), (3000, 1467), (4096, 1989), (6000, 2957), (10000, 4917)):
         p = nb.plan_launch(n, m)
