@@ -154,6 +154,8 @@ def kernel_sources_sha():
     for rel in KERNEL_SOURCES:
         with open(os.path.join(ROOT, rel), "r") as f:
             text = f.read()
+        text = re.sub(r"// NB_HASH_OFF.*?// NB_HASH_ON[^\n]*", "", text, flags=re.S)   # host-side cost model (which shape
+        #                                     it picks is recorded separately, under "launch")
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)     # block comments
         text = re.sub(r"//[^\n]*", "", text)                   # line comments (no string in these files holds "//")
         text = "\n".join(line.strip() for line in text.splitlines() if line.strip())

@@ -572,6 +572,7 @@ const void *pick(int k, int w) {
 
 }  // namespace
 
+// NB_HASH_OFF -- host-side launch-shape arithmetic: not part of the kernel-source hash bench.py ties PMC figures to
 // Launches that do not even fill the chip once with K = 2 / W = 16 workgroups (fewer than 65 536 receivers on 256
 // CUs) are priced in microseconds by a model fitted to exhaustive (K, W, split, unit) scans at N = 250 ... 50 000
 // (tools/sweep_shapes.py; profiles/r02_sweep_shapes_units.txt holds the latest scan, 3 360 timed shapes).  There a wave is
@@ -686,6 +687,7 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
     return best;
 }
 
+// NB_HASH_ON
 const void *step_kernel_fn(LaunchShape s) {
     return s.variant == VARIANT_SMEM ? pick<VARIANT_SMEM>(s.k, s.w) : pick<VARIANT_LDS>(s.k, s.w);
 }
