@@ -1095,7 +1095,8 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world,n,overlap", [(2, 1024, 0), (3, 333, 1), (4, 4096, 1), (3, 4096, 0)])
+# at most 3 ranks: the GPU boxes allow 6 processes on the card, and the pytest process and the torchrun launcher count too
+@pytest.mark.parametrize("world,n,overlap", [(2, 1024, 0), (3, 333, 1), (2, 4096, 1), (3, 4096, 0)])
 def test_sharded_pipeline_with_real_processes_on_one_gpu(golden, tmp_path, world, n, overlap):
     """pipeline.hip's sharded host code with `world` REAL processes (ranks > 0 in their own address space, collective
     Get included), all on this one GPU: the exchange goes through the caller-supplied host transport

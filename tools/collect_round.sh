@@ -36,7 +36,7 @@ NB_HIP_FORCE_SHARDED=1 python -m torch.distributed.run --nnodes=1 --nproc-per-no
 python tools/odd_chain_probe.py > $O/${TAG}_odd_chain_probe.txt 2>&1; echo "odd rc=$?"
 python tools/first_call_probe.py > $O/${TAG}_first_call_probe.txt 2>&1; echo "first-call rc=$?"
 python tools/graph_chunk_probe.py > $O/${TAG}_graph_chunk_probe.txt 2>&1; echo "chunk rc=$?"
-for P in 2 4; do
+for P in 2 3; do
   python -m torch.distributed.run --nnodes=1 --nproc-per-node $P --master-addr 127.0.0.1 --master-port 2954$P bench.py --gpus $P \
       --transport host --steps 10 --warmup 2 > $O/${TAG}_rehearsal_${P}ranks_host.json 2> $O/${TAG}_rehearsal_${P}ranks_host.err; echo "host-transport P=$P rc=$?"
 done
