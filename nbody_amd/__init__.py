@@ -20,7 +20,16 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 HIP_SO = os.environ.get("NBODY_HIP_SO") or os.path.join(LIB_DIR, "libnbody_hip.so")  # override: kernel experiments
 NBODY_SO = os.path.join(LIB_DIR, "libnbody.so")
 
-NB_G = 10.0
+
+
+def _nb_g_from_header():
+    """NB_G as include/nbody.h spells it -- the one place the value is written down."""
+    import re
+    with open(os.path.join(ROOT, "include", "nbody.h")) as f:
+        return float(re.search(r"^#define\s+NB_G\s+([0-9.eE+-]+)f?\s*$", f.read(), re.M).group(1))
+
+
+NB_G = _nb_g_from_header()
 UNIQUE_ID_BYTES = 128
 
 
@@ -180,8 +189,19 @@ class SimPipeline:
         self._cb = None
         if allgather is not None:
             def thunk(_ctx, buf, bytes_per_rank, r, n):
-                rows = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(n, int(bytes_per_rank)))
-                allgather(rows, r, n)
+                # An exception must not escape into ctypes (it would be printed and swallowed, the staging buffer would
+                # keep stale peer slots, and this rank would step on them while the others block in their next
+                # collective).  The process has touched the GPU: report and leave with a fresh exit, no retry.
+                try:
+                    rows = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(n, int(bytes_per_rank)))
+                    allgather(rows, r, n)
+                except BaseException:
+                    import sys
+                    import traceback
+                    traceback.print_exc()
+                    print(f"[nbody_amd] rank {r} of {n}: the caller-supplied all-gather raised; exiting (5)", file=sys.stderr,
+                          flush=True)
+                    os._exit(5)
             self._cb = ALLGATHER_FN(thunk)   # must outlive the pipeline
             self._h = L.CreateSimPipelineShardedWith(wd, rank, nranks, self._cb, None)
         elif nranks > 1 or unique_id is not None:

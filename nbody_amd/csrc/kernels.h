@@ -82,14 +82,14 @@ dim3 finish_grid(uint32_t n_recv);
 dim3 finish_block();
 
 // AoS <-> SoA converters (reference Particle layout, include/nbody.h).
-// split: aos[first .. first+count) -> soa slots [slot0 .. slot0+count); gm = NB_G * mass
+// split: aos[first .. first+count) -> soa slots [slot0 .. slot0+count)
 void launch_split(hipStream_t st, const void *aos, uint32_t first, uint32_t count, float2 *pos, float2 *vel, float2 *acc,
                   float *radius, float *mass, uint32_t slot0);
 // fill pad slots so that they are inert sources / harmless receivers
 void launch_fill_pad(hipStream_t st, float2 *pos, float2 *vel, float2 *acc, float *radius, float *mass, uint32_t slot0,
                      uint32_t count);
-// gm[j] = NB_G * mass[j] for j < count (0 where mass <= 0)
-void launch_make_gm(hipStream_t st, const float *mass, float *gm, uint32_t count);
+// gm[j] = g * mass[j] for j < count (0 where mass <= 0); g = the host's NB_G, the only place the value is written down
+void launch_make_gm(hipStream_t st, const float *mass, float *gm, uint32_t count, float g);
 // merge: soa slots [slot0 .. slot0+count) -> aos[first .. first+count)
 void launch_merge(hipStream_t st, void *aos, uint32_t first, uint32_t count, const float2 *pos, const float2 *vel,
                   const float2 *acc, const float *radius, const float *mass, uint32_t slot0);
@@ -97,6 +97,6 @@ void launch_merge(hipStream_t st, void *aos, uint32_t first, uint32_t count, con
 void launch_set_scalar(hipStream_t st, float *dst, float value);
 // sharded upload: both gathered source arrays + G*m from the AoS world; slots in [mass_len, n_src) become inert pads
 void launch_split_sources(hipStream_t st, const void *aos, uint32_t mass_len, uint32_t n_src, float2 *pos0, float2 *pos1,
-                          float *gm);
+                          float *gm, float g);
 
 }  // namespace nb

@@ -199,25 +199,17 @@ __device__ __forceinline__ void interact(Receivers<K> &R, f2v sxy, float sg) {
 }
 
 // 8 sources (x,y interleaved in P, G*m in G) against the K receivers: 8*K interaction statements, source-major.
+// (Schedule experiments replace this one function from outside the product tree: tools/exp_body_hook.h, force-included
+// by tools/build_variants.sh, defines NB_INTERACT8_OVERRIDE and supplies its own.)
+#ifndef NB_INTERACT8_OVERRIDE
 template <int K, bool SRC_IN_SGPR, typename VP, typename VG>
 __device__ __forceinline__ void interact8(Receivers<K> &R, const VP &P, const VG &G) {
-#ifdef NB_EXPGEN_ASM  // tuning builds only (tools/gen_plain_body.py): NB_EXPGEN_S sources x 2 receivers per generated statement
-    if constexpr (K == 2 && SRC_IN_SGPR) {
-#pragma unroll
-        for (int u = 0; u < 8; u += NB_EXPGEN_S) {
-            asm(NB_EXPGEN_ASM
-                : [ax0] "+v"(R.a[0].x), [ay0] "+v"(R.a[0].y), [ax1] "+v"(R.a[1].x), [ay1] "+v"(R.a[1].y)
-                : [sx0] "s"(P[2 * u]), [sy0] "s"(P[2 * u + 1]), [g0] "s"(G[u]),
-                  [sx1] "s"(P[2 * ((u + 1) & 7)]), [sy1] "s"(P[2 * ((u + 1) & 7) + 1]), [g1] "s"(G[(u + 1) & 7]),
-                  [px0] "v"(R.p[0].x), [py0] "v"(R.p[0].y), [r0] "v"(R.r[0]), [px1] "v"(R.p[1].x), [py1] "v"(R.p[1].y), [r1] "v"(R.r[1])
-                : NB_EXPGEN_CLOBBERS);
-        }
-        return;
-    }
-#endif
 #pragma unroll
     for (int u = 0; u < 8; u++) interact<K, SRC_IN_SGPR>(R, f2v{P[2 * u], P[2 * u + 1]}, G[u]);
 }
+#else
+NB_INTERACT8_OVERRIDE
+#endif
 
 // Slot of logical receiver i (see StepParams::recv_split).
 __device__ __forceinline__ uint32_t receiver_slot(const StepParams &p, uint32_t i) {
@@ -526,17 +518,19 @@ __global__ void fill_pad_kernel(float2 *pos, float2 *vel, float2 *acc, float *ra
 
 __global__ void set_scalar_kernel(float *dst, float value) { *dst = value; }
 
-__global__ void make_gm_kernel(const float *mass, float *gm, uint32_t count) {
+// `g` is the host's NB_G (include/nbody.h), handed in at launch like the reference's specialisation constant
+// (sim_gpu.c:54-72, particle_cs.glsl:26): the device code holds no copy of the value.
+__global__ void make_gm_kernel(const float *mass, float *gm, uint32_t count, float g) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const float m = mass[i];
-    gm[i] = m > 0.0f ? __fmul_rn(m, 10.0f) : 0.0f;  // NB_G * m, rounded as the reference's `gm = m * g`
+    gm[i] = m > 0.0f ? __fmul_rn(m, g) : 0.0f;  // rounded as the reference's `gm = m * g` (sim_cpu.c:179)
 }
 
 // Sharded upload: the gathered source arrays (both ping-pong buffers) and the static G*m straight from the AoS
 // world every rank holds.  Slots past mass_len are pads: far away, finite, massless (exact zero contribution).
 __global__ void split_sources_kernel(const ParticleRec *aos, uint32_t mass_len, uint32_t n_src, float2 *pos0, float2 *pos1,
-                                     float *gm) {
+                                     float *gm, float big_g) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_src) return;
     float2 q = make_float2(1.0e15f, 1.0e15f);
@@ -544,7 +538,7 @@ __global__ void split_sources_kernel(const ParticleRec *aos, uint32_t mass_len, 
     if (i < mass_len) {
         const ParticleRec r = aos[i];
         q = make_float2(r.a.x, r.a.y);
-        g = r.b.z > 0.0f ? __fmul_rn(r.b.z, 10.0f) : 0.0f;  // NB_G * m, rounded as the reference's `gm = m * g`
+        g = r.b.z > 0.0f ? __fmul_rn(r.b.z, big_g) : 0.0f;  // as make_gm_kernel
     }
     pos0[i] = q;
     pos1[i] = q;
@@ -717,9 +711,9 @@ void launch_set_scalar(hipStream_t st, float *dst, float value) {
     hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, st, dst, value);
 }
 
-void launch_make_gm(hipStream_t st, const float *mass, float *gm, uint32_t count) {
+void launch_make_gm(hipStream_t st, const float *mass, float *gm, uint32_t count, float g) {
     if (count == 0) return;
-    hipLaunchKernelGGL(make_gm_kernel, grid1d(count), dim3(256), 0, st, mass, gm, count);
+    hipLaunchKernelGGL(make_gm_kernel, grid1d(count), dim3(256), 0, st, mass, gm, count, g);
 }
 
 void launch_merge(hipStream_t st, void *aos, uint32_t first, uint32_t count, const float2 *pos, const float2 *vel,
@@ -730,10 +724,10 @@ void launch_merge(hipStream_t st, void *aos, uint32_t first, uint32_t count, con
 }
 
 void launch_split_sources(hipStream_t st, const void *aos, uint32_t mass_len, uint32_t n_src, float2 *pos0, float2 *pos1,
-                          float *gm) {
+                          float *gm, float g) {
     if (n_src == 0) return;
     hipLaunchKernelGGL(split_sources_kernel, grid1d(n_src), dim3(256), 0, st, static_cast<const ParticleRec *>(aos), mass_len,
-                       n_src, pos0, pos1, gm);
+                       n_src, pos0, pos1, gm, g);
 }
 
 }  // namespace nb

@@ -1,0 +1,241 @@
+// pipeline_internal.h -- what the translation units behind include/nbody_hip.h share (C++, not part of the C-ABI):
+//
+//   device_ctx.hip   the process-wide device context (the reference keeps one global vulkan_ctx, vulkan_ctx.c:11)
+//   rccl_bind.hip    RCCL bound lazily with dlopen, the communicator of a sharded pipeline, the watchdog
+//   shard_plan.hip   nb_hip_shard_plan: who owns which receivers and sources (pure host arithmetic)
+//   step_chain.hip   one step / n steps as launches, cached hipGraph chains, the sharded step with its all-gather
+//   pipeline.hip     SimPipeline life cycle and the C-ABI entry points (Create/Destroy/Set/Get/PerformSimUpdate, knobs)
+//   kernels.hip      the gfx950 kernels (kernels.h)
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "kernels.h"
+#include "nbody_hip.h"
+
+// ---- error convention: print where, abort (reference src/lib/util.h:17-29,47-60) -------------------------
+
+#define NB_FAIL(...)                                                          \
+    do {                                                                      \
+        fprintf(stderr, "%s:%d [%s] ", __FILE__, __LINE__, __func__);         \
+        fprintf(stderr, __VA_ARGS__);                                         \
+        fprintf(stderr, "\n");                                                \
+        abort();                                                              \
+    } while (0)
+
+#define NB_ASSERT(COND, ...)               \
+    do {                                   \
+        if (!(COND)) NB_FAIL(__VA_ARGS__); \
+    } while (0)
+
+#define ASSERT_HIP(X, ...)                                                                              \
+    do {                                                                                                \
+        hipError_t nb_e_ = (X);                                                                         \
+        if (nb_e_ != hipSuccess) {                                                                      \
+            fprintf(stderr, "%s:%d [%s] hipError_t = %d, str = %s\n", __FILE__, __LINE__, __func__,     \
+                    (int)nb_e_, hipGetErrorString(nb_e_));                                              \
+            NB_FAIL(__VA_ARGS__);                                                                       \
+        }                                                                                               \
+    } while (0)
+
+typedef struct ncclComm *ncclComm_t;  // opaque; rccl_bind.hip holds the rest of the binding
+
+namespace nbi {
+
+// ---- device_ctx.hip ------------------------------------------------------------------------------------------
+
+struct DeviceCtx {
+    bool ready = false;
+    int ordinal = -1;  // -1: not chosen yet
+    int compute_units = 0;
+    char info[256] = {0};
+};
+extern DeviceCtx g_dev;
+extern int g_requested_ordinal;
+
+void ensure_device();  // first touch of the GPU by this process; aborts unless a gfx950 device answers (no CPU fallback)
+void use_device();     // ensure_device + hipSetDevice on the calling thread (HIP's current device is per THREAD)
+void *dev_alloc_bytes(size_t bytes);
+void dev_free(void *p);
+
+template <typename T>
+T *dev_alloc(size_t count) {
+    return static_cast<T *>(dev_alloc_bytes((count ? count : 1) * sizeof(T)));
+}
+
+inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+// ---- rccl_bind.hip -------------------------------------------------------------------------------------------
+
+// A collective that never completes (a rank that died, a fabric that does not come up) must not hang the job: every
+// call that waits on other ranks -- ncclCommInitRank, the first all-gather, and the blocking waits of a sharded
+// pipeline (PerformSimUpdate's sync, the collective GetSimulationData) -- runs under a watchdog that prints what was
+// being waited for, the tail of RCCL's own log when NCCL_DEBUG_FILE names one, and _exit(3)s.  No retry and no
+// re-exec: the process has initialised the GPU.  NB_HIP_COMM_TIMEOUT_S (default 180) sets the bound; 0 disables it.
+class Watchdog {
+  public:
+    Watchdog(const char *what, int rank, int nranks);
+    ~Watchdog();
+    Watchdog(const Watchdog &) = delete;
+    Watchdog &operator=(const Watchdog &) = delete;
+
+  private:
+    void run();
+    const char *what_;
+    int rank_, nranks_, seconds_ = 0;
+    bool done_ = false;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::thread th_;
+};
+
+// ncclCommInitRank + cross-check of the communicator's own rank count + a verified probe all-gather, all bounded
+void comm_create(::SimPipeline *s, const void *unique_id128);
+void comm_destroy(::SimPipeline *s);
+// in-place ncclAllGather of `count` floats per rank (sendbuff = recvbuff + rank * count) on `st`
+void comm_allgather_f32(::SimPipeline *s, void *base, size_t count_per_rank, hipStream_t st, const char *what);
+
+// ---- a cached chain of step launches ---------------------------------------------------------------------------
+
+struct StepGraph {
+    uint32_t n = 0;           // steps in the chain
+    uint32_t passes = 1;      // source passes per step
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<hipGraphNode_t> nodes;  // one kernel node per launch, in order
+    std::vector<nb::StepParams> params; // what each node currently holds
+    int phase = -1;                     // which pos buffer the chain reads first
+    nb::LaunchShape shape = {0, 0, 0, 0, 0};
+    uint64_t last_use = 0;              // for eviction: the cache holds at most GRAPH_CACHE_MAX chains
+};
+
+// Event pairs around the kernels and the gathers of a sharded chain (the plain-launch path, "timing" knob on), so that
+// a multi-GPU run can say how much of a step was the all-gather.  Grown on demand, reused by every call.
+struct EventPool {
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    hipEvent_t next();
+    void destroy();
+};
+
+}  // namespace nbi
+
+struct LocalGroup {
+    std::vector<SimPipeline *> members;
+    hipStream_t stream = nullptr;  // every member enqueues here, so program order is the only ordering needed
+};
+
+struct SimPipeline {
+    WorldData data;
+    // sharding (nranks == 1: the whole world on one device)
+    int rank = 0, nranks = 1;
+    bool sharded = false;  // RCCL path (nranks > 1, or forced for single-GPU testing of that path)
+    NbShardPlan plan;
+    ncclComm_t comm = nullptr;
+    struct LocalGroup *group = nullptr;  // test transport: all ranks are pipelines of this process (no RCCL)
+    // caller-supplied transport (CreateSimPipelineShardedWith): an in-place all-gather over HOST memory; the pipeline
+    // stages each exchange through one page-locked buffer (D2H own slot, wait, callback, H2D the other ranks' slots)
+    NbAllGatherFn host_gather = nullptr;
+    void *host_gather_ctx = nullptr;
+    void *stage = nullptr;        // page-locked staging, max(gathered sources, gathered particle slices) bytes
+    size_t stage_bytes = 0;
+
+    bool on_device = false;  // buffers exist and hold data
+    uint32_t slots = 0;      // receiver slots on this device (allocation; includes a shard's pad slots)
+    uint32_t n_real = 0;     // receivers actually computed (== slots when unsharded)
+    uint32_t n_src = 0;      // sources every receiver sees (mass_len, or the padded gathered length)
+
+    // SoA streams (DESIGN.md "Layout in HBM")
+    float2 *pos[2] = {nullptr, nullptr};
+    float2 *vel = nullptr;
+    float2 *acc = nullptr;
+    float *radius = nullptr;
+    float *mass = nullptr;
+    float2 *src_pos[2] = {nullptr, nullptr};  // sharded only: gathered source positions (ping-pong)
+    float *src_gm = nullptr;
+    // the step size lives in device memory, like the reference's uniform block (sim_gpu.h:8-12): kernels read it
+    // through StepParams::dt, a new value is written in stream order when PerformSimUpdate's dt differs from the last
+    // one enqueued (the reference's re-upload, sim_gpu.c:268-284), and no cached hipGraph ever needs re-patching
+    float *dt_dev = nullptr;
+    float dt_enqueued = 0.0f;
+    bool dt_valid = false;
+    uint32_t dt_uploads = 0;
+    void *aos = nullptr;     // device AoS staging for Set/Get (whole world)
+    void *aos_shard = nullptr;  // sharded only: this rank's slice, uniform size
+    void *host_array = nullptr;  // caller's long-lived particle array (nb_hip_note_host_array), page-locked lazily
+    size_t host_bytes = 0;
+    bool host_pinned = false;
+    void *host_dev = nullptr;    // device-side address of the page-locked array (kernels store to it over PCIe)
+    // eager read-back (knob "readback"): in a frame loop -- every blocking update followed by a Get into the noted
+    // array -- the merge kernel of the NEXT Get is appended to the update's own submission and stores straight into the
+    // noted array, so the Get finds its data already there: one submission + one wait per frame instead of two
+    // (step + wait, then merge + D2H copy + wait).  Frozen since round 2: the GUI it serves is out of scope.
+    int readback = 2;             // 0 never, 1 after every blocking update, 2 auto (after two update->Get pairs in a row)
+    int zero_copy_upload = 1;     // SetSimulationData from the noted array: the split kernel reads host memory directly
+    bool host_current = false;    // the noted array already holds the device's latest state
+    uint32_t updates_since_get = 0, frame_streak = 0;
+    // record the ev_begin / ev_end pair around every chain (nb_hip_last_step_ms) and, on the sharded plain-launch path,
+    // the per-step kernel / gather event pairs (nb_hip_last_step_breakdown).  Off unless asked for: the records cost an
+    // interactive caller 3-7 us per call (profiles/r02_frame_loop_latency.txt).
+    int timing = 0;
+    float2 *parts = nullptr;    // split steps only: [split][n_real] partial sums
+    uint32_t parts_cap = 0;     // float2 elements allocated in parts
+    int cur = 0;             // pos[cur] is the latest state
+
+    hipStream_t stream = nullptr;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    hipEvent_t ev_local = nullptr, ev_gather = nullptr;
+    bool timed = false;
+    uint32_t timed_launches = 0;         // step-kernel launches between ev_begin and ev_end
+    uint32_t timed_finish_launches = 0;  // finish-kernel launches in the same interval (split shapes only)
+    // sharded plain-launch chains: [begin, end) event pairs of each step's kernels and of each gather
+    nbi::EventPool pool;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> kernel_iv, comm_iv;
+    uint32_t detail_steps = 0;  // steps the intervals above cover (capped)
+    uint64_t use_clock = 0;     // ticks once per graph lookup (LRU)
+
+    // knobs
+    int want_variant = nb::VARIANT_SMEM, want_k = 0, want_w = 0, want_split = 0;  // SMEM measures 5-8 % faster than LDS tiles
+    int use_graph = 2, overlap = 0, sharded_graph = 0;  // use_graph: 0 never, 1 always, 2 from a chain length's second use
+    int fused_chain = 2;                                // one-launch n-step chains for one-workgroup worlds: 0 never, 2 auto
+    std::vector<uint32_t> seen_chains;                  // chain lengths already run once as plain launches
+    int want_passes = 0;  // source passes per step (0 = auto: keep each pass's sources within one XCD's L2)
+    double first_gather_ms = 0.0;  // sharded: device time of the probe all-gather at creation (includes lazy setup)
+    nb::LaunchShape last_shape = {0, 0, 0, 0, 0};
+    int want_unit = 0;  // source-slice granule: 0 = auto, else 64 / 32 / 16 / 8
+    uint32_t last_groups = 0;
+    uint32_t fused_steps = 0;   // steps the last update ran inside fused (one-launch) chains
+
+    std::vector<nbi::StepGraph> graphs;
+};
+
+namespace nbi {
+
+// ---- step_chain.hip ------------------------------------------------------------------------------------------
+
+constexpr uint32_t CANON_STEPS = 32;  // length of the prebuilt chain of small worlds (see wants_canonical)
+
+void destroy_graph(StepGraph &g);
+nb::LaunchShape resolve_shape(SimPipeline *s);
+bool wants_canonical(const SimPipeline *s);
+StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchShape sh);
+void upload_dt(SimPipeline *s, float dt);
+// one sharded step of one rank; `cs` carries the gather (the comm stream with RCCL; the group stream locally)
+void sharded_step(SimPipeline *s, nb::LaunchShape sh, float dt, hipStream_t cs, bool detail = false);
+// in-place all-gather of a device array of nranks slots through the caller's host transport
+void host_allgather(SimPipeline *s, void *dev_base, size_t bytes_per_rank, hipStream_t st);
+void enqueue_steps(SimPipeline *s, uint32_t n, float dt);  // what PerformSimUpdate / nb_hip_step_async enqueue
+
+}  // namespace nbi

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generate candidate schedules of the (all-plain) interaction body for K = 2 on the scalar-cache route, as a header for
-`tools/build_variants.sh "name:-include <header>"` (kernels.hip picks it up through NB_EXPGEN_ASM).
+`tools/build_variants.sh "name:-include <header> -include $PWD/tools/exp_body_hook.h"` (the hook replaces kernels.hip's interact8).
 
   grouped S    S sources x 2 receivers per statement: all heads, ONE priority window with all 2*S v_rsq_f32, all tails
   twosrc       the shipped paired body twice in one statement (hipcc's pad after every second source)
