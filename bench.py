@@ -11,17 +11,20 @@ Interactions per step = N * mass_len (what the reference kernels evaluate, parti
 K steps run as ONE PerformSimUpdate(K) call, like the reference harness' update(w, dt, 100) (bench.c:30-33);
 particles are resident in HBM before the timed region (SetSimulationData is outside it).
 
-N = 1: the CPU baseline runs FIRST and the GPU legs last and back to back (headline K steps, two repeats of the
-same K steps for the run-to-run spread, the LDS-tile route for roofline.alt_lds), so the GPU is busy for one
-contiguous stretch an outside sampler can see.
+N = 1: the CPU baseline runs FIRST (the reference's own PackedUpdate object code and, on the same receiver sample and
+thread count, the product's UpdateWorld_CPU), then the GPU legs back to back: headline K steps, two repeats of the same
+K steps (run-to-run spread), the LDS-tile route (roofline.alt_lds), and `extra_configs`: BASELINE.json's other
+single-GPU configurations in the reference harness' shape -- C2 (N = 65 536, one 100-step call after 10 warm-up
+steps), C3 (N = 262 144, a cached hipGraph chain at dt, then the same chain at dt/2), C1 (N = 4 096, the product's
+nbody-bench --cpu, no GPU).
 
 N > 1: strong scaling -- the same 2^20 particles, N/P receivers per GPU, all-gather of source positions
 per step over RCCL inside the library; torch.distributed (gloo) only carries the rendezvous, the barrier
-and the reductions of the timings.  The line then also carries: what the RCCL communicator itself reports
-(`rccl`), per-step kernel and all-gather time (`comm_ms_per_step`, `kernel_ms_per_step` min/max over ranks), a
-self-check that all ranks hold the same state and that it matches a single-GPU run of the same steps
-(`self_check`), and `extra_configs`: the overlapped step at the same N and BASELINE.json's config 5
-(N = 2^22, plain and overlapped) from the same command.
+and the reductions of the timings.  The JSON dict is COMPLETE after the headline leg and the self-check (what the
+RCCL communicator itself reports, per-step kernel / all-gather times, all ranks agree and match a single-GPU run);
+every later leg (`extra_configs`: overlapped step, the chain captured as a hipGraph, BASELINE.json's config 5 at
+N = 2^22 plain and overlapped) runs under a host-side deadline: if one stalls, rank 0 writes the line with what is
+in hand plus "extras_aborted": "<leg>" and every rank leaves with exit code 4 -- a fresh exit, never a re-exec.
 
 Runtime note: under torch.distributed.run torch is imported before libnbody_hip.so is loaded, so the HIP runtime
 and librccl that the data path binds are the ones bundled with the torch wheel (ROCm 7.0 build); a plain
@@ -35,7 +38,9 @@ import datetime
 import hashlib
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -47,6 +52,8 @@ FLOP_PER_INTERACTION = 14        # reference op count, sim_cpu.c:169-188 (SURVEY
 PEAK_FP32_VECTOR_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)"
 N_PARTICLES = 1 << 20
 N_CONFIG5 = 1 << 22
+N_CONFIG2 = 1 << 16
+N_CONFIG3 = 1 << 18
 DT = 0.01
 KERNEL_SOURCES = ("nbody_amd/csrc/kernels.hip", "nbody_amd/csrc/kernels.h")
 
@@ -68,13 +75,20 @@ def make_workload(n, all_massive=False):
     return part, mass_len
 
 
+# ---- CPU baseline ---------------------------------------------------------------------------------------------------
+
+def host_cores():
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(cores, 16))  # the GPU box gives one GPU a 16-CPU share
+
+
 def cpu_baseline(part, mass_len, budget_s=12.0):
-    """Reference AVX path timed on this box's host cores over a bounded sample of the same workload."""
+    """Reference AVX path timed on this box's host cores over a bounded sample of the same workload, and the product's
+    own UpdateWorld_CPU on the same receivers with the same number of threads."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 16))  # the GPU box gives one GPU a 16-CPU share
+    cores = host_cores()
     n = part.shape[0]
     # ~2e9 interactions/s/core (SURVEY.md section 6): size the receiver sample for about budget_s seconds
     recv = int(budget_s * 2.0e9 * cores / max(mass_len, 1))
@@ -94,7 +108,7 @@ def cpu_baseline(part, mass_len, budget_s=12.0):
         # SURVEY.md 8d also asks for the 1-thread figure: ~2 s of the same loop on one core
         recv1 = max(64, min(n, int(2.0 * 2.0e9 / max(mass_len, 1))))
         one = recv1 * mass_len / _time_reference_packedupdate(ob.REF_CPU_SO, part, mass_len, recv1, 1)
-    return {
+    out = {
         "value": recv * mass_len / sec,
         "unit": "interactions/s",
         "cores": threads,
@@ -104,6 +118,39 @@ def cpu_baseline(part, mass_len, budget_s=12.0):
         "sample": f"{recv} of {n} receivers x all {mass_len} sources, one step, AVX (-mavx, no FMA) + {threads} threads"
                   f" ({sec:.2f} s); whole step would take ~{sec * n / recv:.0f} s",
     }
+    try:
+        out["product"] = product_cpu_leg(part, mass_len, recv, threads)
+    except Exception as e:  # pragma: no cover - diagnostic only
+        out["product"] = {"error": str(e)}
+    return out
+
+
+def product_cpu_leg(part, mass_len, recv, threads):
+    """The product's own CPU path (libnbody.so: UpdateWorld_CPU = AVX + OpenMP, bit-exact with the reference's AVX
+    build) on the same receiver sample: a World of the first `recv` partitioned particles holds ALL mass_len sources
+    (massive particles come first) and steps exactly recv x mass_len interactions.  No GPU is touched."""
+    import nbody_amd as nb
+
+    recv = max(recv, mass_len)  # the sources must all be in the World
+    gomp = None
+    for name in ("libgomp.so.1", "libgomp.so"):
+        try:
+            gomp = C.CDLL(name)
+            break
+        except OSError:
+            pass
+    if gomp is not None:
+        gomp.omp_set_num_threads(C.c_int(threads))
+    w = nb.World(part[:recv])
+    try:
+        t0 = time.perf_counter()
+        w.update_cpu(DT, 1)
+        sec = time.perf_counter() - t0
+    finally:
+        w.close()
+    return {"value": recv * mass_len / sec, "unit": "interactions/s", "cores": threads if gomp is not None else None,
+            "kind": "product (UpdateWorld_CPU, nbody_amd/csrc/sim_cpu.c, AVX + OpenMP, bit-exact with the reference AVX build)",
+            "sample": f"World of the first {recv} partitioned particles (all {mass_len} sources), one UpdateWorld_CPU step ({sec:.2f} s)"}
 
 
 def _cpu_model():
@@ -144,9 +191,11 @@ def _time_reference_packedupdate(so, part, mass_len, recv, cores):
     return sec
 
 
+# ---- roofline.traffic: tied to the committed PMC profile ----------------------------------------------------------------
+
 def kernel_sources_sha():
     """sha256 over the kernel sources with comments and blank space removed (editing a comment must not orphan a
-    profile); with the launch shape and the source passes per step (both decided in pipeline.hip, both recorded next
+    profile); with the launch shape and the source passes per step (both decided in step_chain.hip, both recorded next
     to the figure) it is what a committed PMC traffic figure is tied to."""
     import re
 
@@ -163,10 +212,8 @@ def kernel_sources_sha():
     return h.hexdigest()
 
 
-def pmc_traffic(n, shape=None, passes=None):
-    """(HBM bytes per step-kernel launch, note): rocprofv3 PMC passes cannot run inside this process, so the figure comes
-    from the committed profile -- and only counts while the kernel sources still hash to what was profiled and this run
-    launched the same shape with the same number of source passes."""
+def _pmc_record(n, shape=None, passes=None):
+    """(record, note): the committed PMC profile, or None and why it does not apply to this run."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(p):
         return None, "no committed PMC profile"
@@ -182,7 +229,29 @@ def pmc_traffic(n, shape=None, passes=None):
     if rec.get("kernel_sources_sha256") != kernel_sources_sha():
         return None, ("stale: kernel sources changed since the PMC profile " + str(rec.get("source"))
                       + " was taken (tools/profile.sh + tools/summarize_profile.py refresh it)")
-    return rec.get("hbm_bytes_per_launch"), f"from {rec.get('source')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, same sources)"
+    return rec, f"from {rec.get('source')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, same sources)"
+
+
+def pmc_traffic(n, shape=None, passes=None):
+    """(HBM bytes per step-kernel launch, note): rocprofv3 PMC passes cannot run inside this process, so the figure comes
+    from the committed profile -- and only counts while the kernel sources still hash to what was profiled and this run
+    launched the same shape with the same number of source passes."""
+    rec, note = _pmc_record(n, shape, passes)
+    return (rec.get("hbm_bytes_per_launch") if rec else None), note
+
+
+def pmc_traffic_parts(n, shape=None, passes=None):
+    """The same figure taken apart: FETCH_SIZE as counted (raw), with the guide's x2, and WRITE_SIZE -- so a reader can
+    see which part of `traffic` is a measurement and which a correction."""
+    rec, _ = _pmc_record(n, shape, passes)
+    if not rec or "fetch_bytes_raw" not in rec:
+        return None
+    return {"fetch_raw": rec["fetch_bytes_raw"], "fetch_corrected_x2": 2.0 * rec["fetch_bytes_raw"], "write": rec["write_bytes"],
+            "raw_total": rec["fetch_bytes_raw"] + rec["write_bytes"],
+            "note": "traffic = 2 x FETCH_SIZE + WRITE_SIZE.  MI355X_MICROARCH.md calibrates the x2 on 16-B-per-lane "
+                    "coalesced streaming loads; this kernel's global loads are 8-B float2 / 4-B float per lane plus the "
+                    "scalar cache's 64-B line fills (uncalibrated widths), so the corrected figure is an upper bound and "
+                    "raw_total a lower bound.  Either way ~1-2 GB/s of ~8000: HBM does not bound this kernel."}
 
 
 def algorithmic_bytes_per_launch(n, m, passes):
@@ -191,6 +260,45 @@ def algorithmic_bytes_per_launch(n, m, passes):
     reads = n * (12 * passes + 8 * (passes - 1) + 8) + m * 12
     writes = n * (8 * passes + 16)
     return (reads + writes) / passes
+
+
+# ---- deadline guard of the optional legs --------------------------------------------------------------------------------
+
+class LegGuard:
+    """Host-side deadline around every optional leg.  The legs block inside C calls (ctypes releases the GIL), so a
+    Python thread can watch the clock: on expiry rank 0 writes the JSON line with what is in hand plus
+    "extras_aborted", and every rank leaves with os._exit(4) -- a fresh exit (the process has touched the GPU; no
+    re-exec, no retry).  The other ranks wait a moment first so that rank 0's line is out before the launcher reacts."""
+
+    def __init__(self, rank, emit_partial, default_s):
+        self.rank, self.emit_partial, self.default_s = rank, emit_partial, default_s
+        self.lock = threading.Lock()
+        self.leg, self.until = None, None
+        self.thread = threading.Thread(target=self._watch, daemon=True)
+        self.thread.start()
+
+    def arm(self, leg, seconds=None):
+        with self.lock:
+            self.leg, self.until = leg, time.monotonic() + (seconds if seconds else self.default_s)
+
+    def disarm(self):
+        with self.lock:
+            self.leg, self.until = None, None
+
+    def _watch(self):
+        while True:
+            time.sleep(0.2)
+            with self.lock:
+                leg, until = self.leg, self.until
+            if leg is None or time.monotonic() < until:
+                continue
+            print(f"[bench] rank {self.rank}: leg '{leg}' passed its deadline; writing what is in hand and exiting (4)",
+                  file=sys.stderr, flush=True)
+            if self.rank == 0:
+                self.emit_partial(leg)
+            else:
+                time.sleep(3.0)
+            os._exit(4)
 
 
 def main():
@@ -208,12 +316,17 @@ def main():
                          "rehearse the multi-process flow where RCCL refuses duplicate devices")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="headline leg only: no repeats / alt_lds (1 GPU), no self_check / extra_configs (N GPUs)")
+                    help="headline leg only: no repeats / alt_lds / extra_configs (1 GPU), no self_check / extra_configs (N GPUs)")
     ap.add_argument("--all-massive", action="store_true",
                     help="informational N^2 run: every particle is a source (not the BASELINE.json workload)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse the multi-rank control flow (rendezvous, id broadcast, barriers, reductions, JSON keys) "
                          "without touching a GPU: no step runs and the reported value is 0")
+    ap.add_argument("--leg-deadline-s", type=float, default=120.0,
+                    help="N > 1: host-side deadline of every optional leg (below the library's own 180 s collective watchdog)")
+    ap.add_argument("--stall-leg", default=None,
+                    help="rehearsal only (host transport): the all-gather callback never returns during this leg "
+                         "(overlap | sharded_graph | config5), to exercise the deadline path")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -275,10 +388,13 @@ def main():
         assert len(raw) == nb.UNIQUE_ID_BYTES
         return bytes(raw)
 
+    current_leg = {"name": "headline"}
     gloo_gather = None
     if args.transport == "host" and sharded:
         def gloo_gather(rows, r, n):
             """In-place all-gather of host rows over gloo (rows[r] is filled on entry)."""
+            if args.stall_leg and current_leg["name"] == args.stall_leg:
+                time.sleep(3600.0)   # rehearsal of a collective that never completes (--stall-leg)
             if dist is None:
                 return
             mine = torch.from_numpy(rows[r].copy())
@@ -305,14 +421,14 @@ def main():
     if world == 1 and rank == 0 and not args.no_cpu_baseline and not args.dry_run:
         cpu = cpu_baseline(part, mass_len)   # before the GPU legs: those then run back to back
 
-    def timed_leg(sim, steps, warmup):
+    def timed_leg(sim, steps, warmup, dt=DT):
         """W untimed steps, then exactly K steps between barrier + device sync on both sides; max over ranks."""
         if warmup > 0:
-            sim.update(warmup, DT)
+            sim.update(warmup, dt)
         barrier()
         sim.sync()
         t0 = time.perf_counter()
-        sim.update(steps, DT)   # ONE call, K steps, blocking (hipGraph chain / RCCL-stepped chain)
+        sim.update(steps, dt)   # ONE call, K steps, blocking (hipGraph chain / RCCL-stepped chain)
         sim.sync()
         barrier()
         return reduce([time.perf_counter() - t0], "max")[0]
@@ -342,8 +458,10 @@ def main():
             "first_gather_ms_rank0": info["first_gather_ms"],
         }
 
+    # ---- the headline leg ---------------------------------------------------------------------------------------
     extras = {}
     steps_done = 0
+    sim = None
     if args.dry_run:
         uid = new_unique_id() if sharded else None
         assert uid is None or len(uid) == nb.UNIQUE_ID_BYTES
@@ -360,18 +478,6 @@ def main():
                               "ranks_with_communicator": 0, "version": None, "lib": None, "first_gather_ms_rank0": None}
             zero = {"min": 0.0, "max": 0.0}
             extras["comm_ms_per_step"], extras["kernel_ms_per_step"] = dict(zero), dict(zero)
-            if not args.no_extras:
-                digest = hashlib.sha256(part.tobytes()).digest()
-                extras["self_check"] = {"ranks_agree": _digests_agree(dist, torch, digest), "vs_single_gpu_rel_l2_pos": None}
-                part5, m5 = make_workload(args.n5)
-                _ = new_unique_id()
-                p5 = nb.shard_plan(part5.shape[0], m5, rank, world)
-                assert p5["src_padded"] >= m5
-                extras["extra_configs"] = [
-                    _extra_entry(n, mass_len, 1, args.steps, 0.0, None, world),
-                    _extra_entry(part5.shape[0], m5, 0, 3, 0.0, None, world),
-                    _extra_entry(part5.shape[0], m5, 1, 3, 0.0, None, world),
-                ]
         runtime = None
     else:
         sim = make_sim(n, mass_len)
@@ -386,53 +492,26 @@ def main():
         info = nb.device_info()
         runtime = {"hip_runtime_version": int(nb.hip_lib().nb_hip_runtime_version()),
                    "torch_imported_first": torch is not None}
-
         if sharded:
             extras["rccl"] = comm_evidence(sim)
             d = sharded_detail(sim, args.steps)
             extras["comm_ms_per_step"], extras["kernel_ms_per_step"] = d["comm_ms_per_step"], d["kernel_ms_per_step"]
-            if not args.no_extras:
-                # every rank must hold the same full state, and it must be the single-GPU state of the same steps
-                got = sim.get_data()  # collective
-                check = {"ranks_agree": _digests_agree(dist, torch, hashlib.sha256(got.tobytes()).digest()),
-                         "steps": steps_done}
-                if rank == 0:
-                    one = nb.SimPipeline(n, mass_len)
-                    one.set_data(part)
-                    one.update(steps_done, DT)
-                    want = one.get_data()
-                    one.close()
-                    dp = (got[:, 0:2].astype(np.float64) - want[:, 0:2]).ravel()
-                    check["vs_single_gpu_rel_l2_pos"] = float(np.sqrt(dp @ dp) / np.linalg.norm(want[:, 0:2].astype(np.float64)))
-                    check["vs_single_gpu_max_abs_pos"] = float(np.abs(dp).max())
-                    check["static_fields_equal"] = bool(np.array_equal(got[:, 6:8], want[:, 6:8]))
-                barrier()
-                extras["self_check"] = check
-                # the overlapped step on the same pipeline
-                sim.configure(overlap=1)
-                e1 = timed_leg(sim, args.steps, 1)
-                extra = [_extra_entry(n, mass_len, 1, args.steps, e1, sharded_detail(sim, args.steps), world)]
-                sim.close()
-                sim = None
-                # BASELINE.json config 5: N = 2^22, plain and overlapped (own communicator: a second ncclCommInitRank)
-                part5, m5 = make_workload(args.n5)
-                sim5 = make_sim(part5.shape[0], m5)
-                sim5.set_data(part5)
-                for ov in (0, 1):
-                    sim5.configure(overlap=ov)
-                    e5 = timed_leg(sim5, 3, 1)
-                    extra.append(_extra_entry(part5.shape[0], m5, ov, 3, e5, sharded_detail(sim5, 3), world))
-                sim5.close()
-                extras["extra_configs"] = extra
-        elif not args.no_extras:
-            # same K steps twice more (run-to-run spread), then the LDS-tile route of the north star on the same chain
-            extras["repeat_ms_per_step"] = [timed_leg(sim, args.steps, 0) / args.steps * 1e3 for _ in range(2)]
-            sim.configure(variant=0)
-            e_lds = timed_leg(sim, args.steps, 2)
-            lds_ms, lds_launches = sim.last_step_ms()
-            extras["alt_lds"] = (e_lds, lds_ms, lds_launches, sim.launch_shape())
-        if sim is not None:
-            sim.close()
+
+    # ---- the JSON dict: complete from here on; later legs only add keys -----------------------------------------
+    out = {}
+    out_lock = threading.Lock()
+    emitted = {"done": False}
+
+    def emit(extra_keys=None):
+        """Write the one line (rank 0, once)."""
+        with out_lock:
+            if emitted["done"] or rank != 0:
+                return
+            emitted["done"] = True
+            line = dict(out)
+            if extra_keys:
+                line.update(extra_keys)
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
 
     if rank == 0:
         interactions = float(n) * float(mass_len) * args.steps
@@ -442,8 +521,8 @@ def main():
         launch_interactions = float(n) * float(mass_len) / world * (args.steps / max(launches, 1))
         achieved_tflops = launch_interactions * FLOP_PER_INTERACTION / per_launch_s / 1e12 if per_launch_s > 0 else 0.0
         passes = max(launches // max(args.steps, 1), 1)
-        traffic, traffic_note = (None, "not measured for this workload") if (args.all_massive or world > 1 or args.dry_run) \
-            else pmc_traffic(n, shape, passes)
+        unmeasured = args.all_massive or world > 1 or args.dry_run
+        traffic, traffic_note = (None, "not measured for this workload") if unmeasured else pmc_traffic(n, shape, passes)
         roof = {
             "bound": "valu",  # fp32 vector ALU (rsq + fma); neither HBM nor MFMA bounds this path
             "achieved": achieved_tflops,
@@ -452,6 +531,7 @@ def main():
             "frac": achieved_tflops / PEAK_FP32_VECTOR_TFLOPS,
             "traffic": traffic,
             "traffic_note": traffic_note,
+            "traffic_parts": None if unmeasured else pmc_traffic_parts(n, shape, passes),
             "traffic_algorithmic": algorithmic_bytes_per_launch(n, mass_len, passes) if world == 1 else None,
             "flop_per_interaction": FLOP_PER_INTERACTION,
             "kernel_ms_per_launch": per_launch_s * 1e3,
@@ -462,57 +542,233 @@ def main():
                                   if finish_launches else "")
                                + ("; sharded: the interval includes the all-gathers, see kernel_ms_per_step" if sharded else "")),
         }
-        if "alt_lds" in extras:
-            e_lds, lds_ms, lds_launches, lds_shape = extras.pop("alt_lds")
-            lds_s = lds_ms * 1e-3 / max(lds_launches, 1)
-            lds_tf = float(n) * float(mass_len) * (args.steps / max(lds_launches, 1)) * FLOP_PER_INTERACTION / lds_s / 1e12
-            roof["alt_lds"] = {"note": "same K steps through the LDS-tile source route (north star's design; variant=0), "
-                                       "bit-identical results, timed after the headline leg",
-                               "ms_per_step": e_lds / args.steps * 1e3, "value": interactions / e_lds,
-                               "kernel_ms_per_launch": lds_s * 1e3, "achieved": lds_tf,
-                               "frac": lds_tf / PEAK_FP32_VECTOR_TFLOPS, "kernel": lds_shape}
-        out = {
-            "metric": "particle-pair interactions/sec at N=2^20",
-            "value": value,
-            "unit": "interactions/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "steps_per_sec": args.steps / elapsed,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": f"srand(11037) MakeGalaxies({n}, 2) (galaxy.h ICs)"
-                            f"{', massless half given NP_R_TO_M(radius) mass (all-massive N^2 run)' if args.all_massive else ''}"
-                            f", partitioned; N={n}, mass_len={mass_len}, "
-                            f"dt={DT}; {n * mass_len:.4g} interactions/step; one PerformSimUpdate({args.steps}) call",
-                "parallelism": (f"receivers sharded N/{world} per GPU, all-gather of source positions per step"
-                                + (" over the caller-supplied HOST transport (gloo; rehearsal, not RCCL)" if gloo_gather else ""))
-                               if world > 1 else "single GPU",
-                "kernel": shape,
-                "device": info,
-            },
-            "roofline": roof,
-            "runtime": runtime,
-        }
-        if sharded:
-            # ncclCommCount as seen by every rank's communicator -- null when a rank holds none (host transport, dry run)
-            out["rccl_nranks"] = (extras["rccl"]["nranks_reported"]["min"]
-                                  if extras["rccl"]["ranks_with_communicator"] == world else None)
-            out["transport"] = "host (gloo all-gather through page-locked staging)" if gloo_gather else "rccl (in-stream ncclAllGather)"
-        out.update(extras)
-        if cpu is not None:
-            out["cpu_baseline"] = cpu
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        with out_lock:
+            out.update({
+                "metric": "particle-pair interactions/sec at N=2^20",
+                "value": value,
+                "unit": "interactions/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": elapsed / args.steps * 1e3,
+                "steps_per_sec": args.steps / elapsed,
+                "higher_is_better": True,
+                "scaling": "strong",
+                "vs_baseline": None,
+                "dtype": "f32",
+                "data": "synthetic",
+                "config": {
+                    "workload": f"srand(11037) MakeGalaxies({n}, 2) (galaxy.h ICs)"
+                                f"{', massless half given NP_R_TO_M(radius) mass (all-massive N^2 run)' if args.all_massive else ''}"
+                                f", partitioned; N={n}, mass_len={mass_len}, "
+                                f"dt={DT}; {n * mass_len:.4g} interactions/step; one PerformSimUpdate({args.steps}) call",
+                    "parallelism": (f"receivers sharded N/{world} per GPU, all-gather of source positions per step"
+                                    + (" over the caller-supplied HOST transport (gloo; rehearsal, not RCCL)" if gloo_gather else ""))
+                                   if world > 1 else "single GPU",
+                    "kernel": shape,
+                    "device": info,
+                },
+                "roofline": roof,
+                "runtime": runtime,
+            })
+            if sharded:
+                # ncclCommCount as seen by every rank's communicator -- null when a rank holds none (host transport, dry run)
+                out["rccl_nranks"] = (extras["rccl"]["nranks_reported"]["min"]
+                                      if extras["rccl"]["ranks_with_communicator"] == world else None)
+                out["transport"] = ("host (gloo all-gather through page-locked staging)" if gloo_gather
+                                    else "rccl (in-stream ncclAllGather)")
+            out.update(extras)
+            if cpu is not None:
+                out["cpu_baseline"] = cpu
+
+    def put(key, val):
+        if rank == 0:
+            with out_lock:
+                out[key] = val
+
+    # ---- optional legs ------------------------------------------------------------------------------------------
+    if sharded and not args.no_extras:
+        guard = LegGuard(rank, lambda leg: emit({"extras_aborted": leg}), args.leg_deadline_s) if not args.dry_run else None
+
+        def leg(name):
+            current_leg["name"] = name
+            if guard:
+                guard.arm(name)
+
+        if args.dry_run:
+            digest = hashlib.sha256(part.tobytes()).digest()
+            put("self_check", {"ranks_agree": _digests_agree(dist, torch, digest), "vs_single_gpu_rel_l2_pos": None})
+            part5, m5 = make_workload(args.n5)
+            _ = new_unique_id()
+            p5 = nb.shard_plan(part5.shape[0], m5, rank, world)
+            assert p5["src_padded"] >= m5
+            put("extra_configs", [
+                _extra_entry(n, mass_len, 1, 0, args.steps, 0.0, None, world),
+                _extra_entry(n, mass_len, 0, 1, args.steps, 0.0, None, world),
+                _extra_entry(part5.shape[0], m5, 0, 0, 3, 0.0, None, world),
+                _extra_entry(part5.shape[0], m5, 1, 0, 3, 0.0, None, world),
+            ])
+        else:
+            # every rank must hold the same full state, and it must be the single-GPU state of the same steps
+            leg("self_check")
+            got = sim.get_data()  # collective
+            check = {"ranks_agree": _digests_agree(dist, torch, hashlib.sha256(got.tobytes()).digest()),
+                     "steps": steps_done}
+            if rank == 0:
+                one = nb.SimPipeline(n, mass_len)
+                one.set_data(part)
+                one.update(steps_done, DT)
+                want = one.get_data()
+                one.close()
+                dp = (got[:, 0:2].astype(np.float64) - want[:, 0:2]).ravel()
+                check["vs_single_gpu_rel_l2_pos"] = float(np.sqrt(dp @ dp) / np.linalg.norm(want[:, 0:2].astype(np.float64)))
+                check["vs_single_gpu_max_abs_pos"] = float(np.abs(dp).max())
+                check["static_fields_equal"] = bool(np.array_equal(got[:, 6:8], want[:, 6:8]))
+            barrier()
+            put("self_check", check)
+            extra = []
+            put("extra_configs", extra)   # the list grows in place: a deadline line carries the legs that finished
+            # the overlapped step on the same pipeline
+            leg("overlap")
+            sim.configure(overlap=1)
+            e1 = timed_leg(sim, args.steps, 1)
+            extra.append(_extra_entry(n, mass_len, 1, 0, args.steps, e1, sharded_detail(sim, args.steps), world))
+            # north star: "multi-step chains are captured as hipGraph" -- the {kernel, all-gather} x K chain captured
+            # from the stream and replayed (RCCL inside stream capture; a host callback cannot be captured)
+            leg("sharded_graph")
+            sim.configure(overlap=0)
+            if gloo_gather is None:
+                sim.configure(sharded_graph=1)
+                eg = timed_leg(sim, args.steps, args.steps)   # the warm-up call captures and instantiates the chain
+                entry = _extra_entry(n, mass_len, 0, 1, args.steps, eg, None, world)
+                entry["graph_stats"] = sim.graph_stats()
+                extra.append(entry)
+                sim.configure(sharded_graph=0)
+            else:
+                if args.stall_leg == "sharded_graph":
+                    sim.update(1, DT)
+                extra.append(dict(_extra_entry(n, mass_len, 0, 1, args.steps, 0.0, None, world),
+                                  skipped="host transport: a host callback cannot run inside a captured graph"))
+            sim.close()
+            sim = None
+            # BASELINE.json config 5: N = 2^22, plain and overlapped (own communicator: a second ncclCommInitRank)
+            leg("config5")
+            part5, m5 = make_workload(args.n5)
+            sim5 = make_sim(part5.shape[0], m5)
+            sim5.set_data(part5)
+            for ov in (0, 1):
+                leg("config5")
+                sim5.configure(overlap=ov)
+                e5 = timed_leg(sim5, 3, 1)
+                extra.append(_extra_entry(part5.shape[0], m5, ov, 0, 3, e5, sharded_detail(sim5, 3), world))
+            sim5.close()
+            if guard:
+                guard.disarm()
+    elif not sharded and not args.no_extras and not args.dry_run:
+        # same K steps twice more (run-to-run spread), then the LDS-tile route of the north star on the same chain
+        put("repeat_ms_per_step", [timed_leg(sim, args.steps, 0) / args.steps * 1e3 for _ in range(2)])
+        sim.configure(variant=0)
+        e_lds = timed_leg(sim, args.steps, 2)
+        lds_ms, lds_launches = sim.last_step_ms()
+        lds_s = lds_ms * 1e-3 / max(lds_launches, 1)
+        lds_tf = float(n) * float(mass_len) * (args.steps / max(lds_launches, 1)) * FLOP_PER_INTERACTION / lds_s / 1e12
+        if rank == 0:
+            with out_lock:
+                out["roofline"]["alt_lds"] = {
+                    "note": "same K steps through the LDS-tile source route (north star's design; variant=0), bit-identical "
+                            "results, timed after the headline leg; why it trails: profiles/r03_routes_pmc.txt",
+                    "ms_per_step": e_lds / args.steps * 1e3, "value": float(n) * float(mass_len) * args.steps / e_lds,
+                    "kernel_ms_per_launch": lds_s * 1e3, "achieved": lds_tf,
+                    "frac": lds_tf / PEAK_FP32_VECTOR_TFLOPS, "kernel": sim.launch_shape()}
+        sim.close()
+        sim = None
+        if not args.all_massive and args.n == N_PARTICLES:
+            put("extra_configs", single_gpu_configs(nb))
+    if sim is not None:
+        sim.close()
+
+    emit()
 
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def single_gpu_configs(nb):
+    """BASELINE.json's other single-GPU configurations, in the shape of the reference harness (src/bench.c:21-35)."""
+    out = []
+
+    def rate(n, m, sec_per_step):
+        v = float(n) * float(m) / sec_per_step
+        return {"ms_per_step": sec_per_step * 1e3, "value": v, "unit": "interactions/s",
+                "roofline_frac": v * FLOP_PER_INTERACTION / (PEAK_FP32_VECTOR_TFLOPS * 1e12)}
+
+    # C2: N = 65 536, one kernel per step; 10 warm-up steps, then ONE 100-step call, library defaults (what
+    # nbody-bench's single timed call gets: plain launches the first time a chain length is seen, bench.c:30-33)
+    part, m = make_workload(N_CONFIG2)
+    n = part.shape[0]
+    sim = nb.SimPipeline(n, m)
+    sim.set_data(part)
+    sim.update(10, DT)
+    t0 = time.perf_counter()
+    sim.update(100, DT)
+    first = (time.perf_counter() - t0) / 100
+    k_ms, launches = sim.last_step_ms()
+    later = []
+    for _ in range(3):   # from its second use the same chain length replays as a cached hipGraph
+        t0 = time.perf_counter()
+        sim.update(100, DT)
+        later.append((time.perf_counter() - t0) / 100)
+    entry = {"config": "C2", "workload": f"srand(11037) MakeGalaxies({n}, 2), N={n}, mass_len={m}, dt={DT}; 10 warm-up steps, "
+                                         "one PerformSimUpdate(100) call, default knobs",
+             "steps": 100, "kernel": sim.launch_shape(), "kernel_ms_per_launch": k_ms / max(launches, 1),
+             "launches": launches, "graph_stats": sim.graph_stats()}
+    entry.update(rate(n, m, first))
+    entry["later_calls"] = dict(rate(n, m, min(later)), note="fastest of 3 further 100-step calls (cached hipGraph replays)")
+    sim.close()
+    out.append(entry)
+
+    # C3: N = 262 144, the K-step chain as a hipGraph: built by a warm-up call, replayed at dt, then the SAME cached
+    # chain at dt/2 (the step size lives in device memory: one 4-byte upload, no rebuild, no node patched)
+    part, m = make_workload(N_CONFIG3)
+    n = part.shape[0]
+    sim = nb.SimPipeline(n, m)
+    sim.configure(graph=1)
+    sim.set_data(part)
+    k = 20
+    sim.update(k, DT)          # builds + instantiates the 20-step chain
+    g0 = sim.graph_stats()
+    t0 = time.perf_counter()
+    sim.update(k, DT)
+    at_dt = (time.perf_counter() - t0) / k
+    k_ms, launches = sim.last_step_ms()
+    t0 = time.perf_counter()
+    sim.update(k, DT / 2)
+    at_half = (time.perf_counter() - t0) / k
+    g1 = sim.graph_stats()
+    entry = {"config": "C3", "workload": f"srand(11037) MakeGalaxies({n}, 2), N={n}, mass_len={m}; one cached {k}-step hipGraph "
+                                         f"chain replayed at dt={DT}, then at dt={DT / 2}",
+             "steps": k, "kernel": sim.launch_shape(), "kernel_ms_per_launch": k_ms / max(launches, 1), "launches": launches,
+             "graph_stats_before": g0, "graph_stats_after": g1,
+             "chain_rebuilt_for_new_dt": g1["cached"] != g0["cached"], "dt_uploads_for_new_dt": g1["dt_uploads"] - g0["dt_uploads"]}
+    entry.update(rate(n, m, at_dt))
+    entry["dt_halved"] = rate(n, m, at_half)
+    sim.close()
+    out.append(entry)
+
+    # C1: N = 4 096 on the CPU path through the product's nbody-bench (plumbing; no GPU involved)
+    exe = os.path.join(ROOT, "nbody_amd", "lib", "nbody-bench")
+    try:
+        env = dict(os.environ, OMP_NUM_THREADS=str(host_cores()))
+        r = subprocess.run([exe, "--cpu", "--n", "4096", "--steps", "100"], env=env, capture_output=True, text=True, timeout=120)
+        row = [line.split() for line in r.stdout.splitlines() if line.split() and line.split()[0] == "4096"][0]
+        out.append({"config": "C1", "workload": "nbody-bench --cpu --n 4096 --steps 100 (srand(11037) MakeGalaxies(4096, 2), dt=1, "
+                                                "10 warm-up + 100 timed steps, UpdateWorld_CPU = AVX + OpenMP)",
+                    "steps": 100, "us_per_step": float(row[1]), "value": float(row[2]), "unit": "interactions/s",
+                    "cores": host_cores()})
+    except Exception as e:  # pragma: no cover - diagnostic only
+        out.append({"config": "C1", "error": str(e)})
+    return out
 
 
 def _digests_agree(dist, torch, digest):
@@ -527,10 +783,11 @@ def _digests_agree(dist, torch, digest):
     return bool(same.item() == 1.0)
 
 
-def _extra_entry(n, m, overlap, steps, elapsed, detail, world):
+def _extra_entry(n, m, overlap, sharded_graph, steps, elapsed, detail, world):
     e = {
         "workload": f"srand(11037) MakeGalaxies({n}, 2), N={n}, mass_len={m}, dt={DT}, N/{world} receivers per GPU",
         "overlap": overlap,   # 1 = own-shard kernel runs while the other shards' positions are still being gathered
+        "sharded_graph": sharded_graph,   # 1 = the {kernel, all-gather} x K chain captured as a hipGraph and replayed
         "steps": steps,
         "ms_per_step": elapsed / steps * 1e3,
         "steps_per_sec": steps / elapsed if elapsed > 0 else 0.0,

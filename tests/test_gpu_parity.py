@@ -6,13 +6,15 @@ where acc_f64 is the oracle's float64 evaluation of the same sum.  The reference
 builds differ from each other by the same order (2.9e-6 .. 1.4e-5 relative).  The integrator is
 then exact fp32 arithmetic on that acc with the reference's roundings (sim_cpu.c:191-193: mul, then add),
 checked bit for bit: vel == vel0 + acc*dt and pos == pos0 + vel*dt.
-Ten steps at dt = 0.01: relative L2 over all positions <= 1e-6.  Nothing is asserted on 100-step
-trajectories (chaotic).  Integer-like facts (partition order, mass, radius, pass-through) are bit-exact.
+Ten steps at dt = 0.01: relative L2 over all positions <= 1e-6 AND, the sharp one, relative to what the steps moved:
+|(pos - pos0)_gpu - (pos - pos0)_ref| / |(pos - pos0)_ref| <= 1e-4 (rel_displacement; the reference's own sequential
+and AVX orders differ by 8.7e-7 there).  Nothing is asserted on 100-step trajectories (chaotic).  Integer-like facts (partition order, mass, radius, pass-through) are bit-exact.
 """
 import ctypes as C
 import os
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -59,6 +61,21 @@ def run(part, m, n, dt, **knobs):
     return out
 
 
+def rel_displacement(got, want, start):
+    """Multi-step parity metric relative to what the steps MOVED, not to where the particles are:
+    |(pos - pos0)_gpu - (pos - pos0)_ref| / |(pos - pos0)_ref| over all particles.  Relative to the positions
+    themselves (1e4..1e6) ten steps at dt = 0.01 are a 1e-4 perturbation, so "rel L2 of pos <= 1e-6" would still pass
+    with gravity switched off (5.5e-4 on this metric's scale); the reference's own sequential and AVX summation orders
+    differ by 8.7e-7 here (reference world.c:99-110 semantics, ten calls of the step)."""
+    p0 = start[:, 0:2].astype(np.float64)
+    dg = got[:, 0:2].astype(np.float64) - p0
+    dw = want[:, 0:2].astype(np.float64) - p0
+    return float(np.linalg.norm(dg - dw) / np.linalg.norm(dw))
+
+
+DISPLACEMENT_TOL = 1e-4   # stated multi-step tolerance (README / DESIGN.md section 5); observed ~1e-6
+
+
 def synth(n, frac_massive=0.5, seed=0, extent=1.0e4):
     rng = np.random.default_rng(seed)
     a = np.zeros((n, 8), dtype=np.float32)
@@ -95,6 +112,13 @@ def test_ten_steps_against_reference_fixture(golden, manifest, n, variant):
     assert rel <= 1e-6, rel
     relv = np.linalg.norm(got[:, 2:4] - want[:, 2:4]) / np.linalg.norm(want[:, 2:4])
     assert relv <= 1e-5, relv
+    # the sharp one: relative to the ten steps' displacement
+    assert rel_displacement(got, want, part) <= DISPLACEMENT_TOL, rel_displacement(got, want, part)
+    # and the metric does see the physics: a run with all masses zeroed (straight lines) fails it by a wide margin
+    straight = part[:, 0:2].astype(np.float64) + 10 * 0.01 * part[:, 2:4].astype(np.float64)
+    fake = got.copy()
+    fake[:, 0:2] = straight
+    assert rel_displacement(fake, want, part) > 10 * DISPLACEMENT_TOL
 
 
 def test_three_steps_dt005_fixture(golden, manifest):
@@ -102,6 +126,7 @@ def test_three_steps_dt005_fixture(golden, manifest):
     want = golden(manifest["sets"]["333"]["steps"]["s3_dt0.05"]["file"]).astype(np.float64)
     got = run(part, m, 3, 0.05).astype(np.float64)
     assert np.linalg.norm(got[:, 0:2] - want[:, 0:2]) / np.linalg.norm(want[:, 0:2]) <= 1e-6
+    assert rel_displacement(got, want, part) <= DISPLACEMENT_TOL
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -582,18 +607,22 @@ def test_negative_mass_is_massless():
 # BASELINE.json sizes: spot-checked against float64 on a receiver sample + size-independent properties
 # ---------------------------------------------------------------------------------------------------------------
 
+@pytest.mark.parametrize("variant", [1, 0], ids=["scalar-cache", "lds-tiles"])
 @pytest.mark.parametrize("n,steps,dt", [(65536, 1, 0.01), (262144, 4, 0.005), (1 << 20, 1, 0.01)])
-def test_baseline_sizes_spot_check(n, steps, dt):
+def test_baseline_sizes_spot_check(n, steps, dt, variant):
+    """Both source routes -- the default scalar-cache one and the north star's LDS-staged tiles -- against float64 at
+    every single-GPU BASELINE size."""
     ic = nb.make_galaxies(n, 2, seed=11037)          # the bench's universe
     w = nb.World(ic)
     part = w.particles()
     m = int((part[:, 6] > 0).sum())
     w.close()
     sim = nb.SimPipeline(n, m)
-    sim.configure(graph=1)                            # chains as hipGraphs from their first use (config 3)
+    sim.configure(graph=1, variant=variant)           # chains as hipGraphs from their first use (config 3)
     sim.set_data(part)
     sim.update(1, dt)
     one = sim.get_data()
+    assert sim.launch_shape()["variant"] == ("smem" if variant else "lds")
     rng = np.random.default_rng(n)
     idx = np.unique(np.concatenate([[0, 1, m - 1, m, n - 1], rng.integers(0, n, 500)])).astype(np.uint32)
     acc64, mag = ob.acc_f64_subset(part, m, idx)
@@ -642,6 +671,7 @@ def test_ten_steps_at_config2_size_against_the_avx_path():
     want = ob.step(part, m, 0.01, 10, kind="avx")
     got = run(part, m, 10, 0.01)
     assert rel_l2_pos(got, want) <= 1e-6
+    assert rel_displacement(got, want, part) <= DISPLACEMENT_TOL, rel_displacement(got, want, part)
     dv = got[:, 2:4].astype(np.float64) - want[:, 2:4]
     assert np.linalg.norm(dv) / np.linalg.norm(want[:, 2:4].astype(np.float64)) <= 1e-4
     assert np.array_equal(got[:, 6:8], want[:, 6:8])
@@ -653,6 +683,7 @@ def test_ten_steps_at_config2_size_against_the_avx_path():
         g.close()
         assert rel_l2_pos(sharded, want) <= 1e-6, f"P=8 overlap={overlap}"
         assert rel_l2_pos(sharded, got) <= 1e-6
+        assert rel_displacement(sharded, want, part) <= DISPLACEMENT_TOL, f"P=8 overlap={overlap}"
         assert np.array_equal(sharded[:, 6:8], want[:, 6:8])
 
 
@@ -784,6 +815,7 @@ def test_local_shard_group_default_shape_within_tolerance(golden, P, overlap, sp
     check_one_step(got, part, m, 0.01)
     want = ob.step(part, m, 0.01, 10).astype(np.float64)
     assert np.linalg.norm(ten[:, 0:2] - want[:, 0:2]) / np.linalg.norm(want[:, 0:2]) <= 1e-6
+    assert rel_displacement(ten, want, part) <= DISPLACEMENT_TOL
 
 
 @pytest.mark.parametrize("overlap", [0, 1])
@@ -1143,5 +1175,56 @@ def test_bench_with_two_real_ranks_on_one_gpu():
     assert check["ranks_agree"] is True and check["static_fields_equal"] is True and check["steps"] == 5
     assert check["vs_single_gpu_rel_l2_pos"] <= 1e-6
     assert out["kernel_ms_per_step"]["min"] > 0 and out["comm_ms_per_step"]["max"] > 0
-    assert [e["overlap"] for e in out["extra_configs"]] == [1, 0, 1]
-    assert all(e["value"] > 1e10 and e["kernel_ms_per_step"]["max"] > 0 for e in out["extra_configs"])
+    extra = out["extra_configs"]
+    assert [(e["overlap"], e["sharded_graph"]) for e in extra] == [(1, 0), (0, 1), (0, 0), (1, 0)]
+    assert "skipped" in extra[1]              # a host callback cannot be captured into a hipGraph: RCCL transport only
+    timed = [e for e in extra if "skipped" not in e]
+    assert all(e["value"] > 1e10 and e["kernel_ms_per_step"]["max"] > 0 for e in timed)
+    assert "extras_aborted" not in out
+
+
+def test_bench_line_survives_a_stuck_leg():
+    """The first real multi-GPU run must not lose its headline to a stalled optional leg: the JSON dict is complete
+    after the headline leg + self-check, every later leg runs under a host-side deadline, and on expiry rank 0 writes
+    the line with what is in hand plus "extras_aborted" and every rank leaves with a fresh non-zero exit.  Rehearsed
+    with two real ranks on this one GPU: during the 'overlap' leg the host transport's all-gather never returns."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29743", os.path.join(nb.ROOT, "bench.py"), "--gpus", "2", "--transport", "host",
+           "--steps", "4", "--warmup", "1", "--particles", "65536", "--extra-particles", "131072",
+           "--stall-leg", "overlap", "--leg-deadline-s", "10"]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=nb.ROOT)
+    assert r.returncode != 0, "a run whose leg stalled must not report success"
+    assert time.time() - t0 < 300, "the deadline, not the 900 s gloo timeout, must end the run"
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(lines[0])
+    assert out["extras_aborted"] == "overlap"
+    assert out["n_gpus"] == 2 and out["value"] > 1e10 and out["ms_per_step"] > 0      # the headline survived
+    assert out["self_check"]["ranks_agree"] is True and out["self_check"]["vs_single_gpu_rel_l2_pos"] <= 1e-6
+    assert out["extra_configs"] == []                                                   # no leg had finished yet
+    assert "passed its deadline" in r.stderr
+
+
+def test_host_transport_callback_that_raises_ends_the_process(golden, tmp_path):
+    """A Python exception inside the caller-supplied all-gather must not escape into ctypes (it would be swallowed
+    and the pipeline would step on stale peer slots): the thunk prints the traceback and leaves with exit code 5."""
+    worker = tmp_path / "raises.py"
+    worker.write_text(r'''
+import os, sys, numpy as np
+root = sys.argv[1]
+sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, root)
+import nbody_amd as nb, oracle_binding as ob
+part, m = ob.partition(np.fromfile(os.path.join(root, "tests", "golden", "ic_333.bin"), dtype=np.float32).reshape(-1, 8))
+def bad(rows, r, n):
+    raise RuntimeError("transport fell over")
+sim = nb.SimPipeline(333, m, rank=0, nranks=1, allgather=bad)
+sim.set_data(part)
+sim.update(1, 0.01)
+print("NOT REACHED")
+''')
+    r = subprocess.run([sys.executable, str(worker), nb.ROOT], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 5, (r.returncode, r.stderr[-2000:])
+    assert "transport fell over" in r.stderr and "all-gather raised" in r.stderr and "NOT REACHED" not in r.stdout

@@ -120,3 +120,32 @@ def test_interaction_body_is_the_twelve_instruction_sequence(isa):
     for a, b in zip(rsq, rsq[1:]):
         if b - a <= 14:
             assert not any(op.startswith("v_pk_") for op in ops[a:b]), ops[a:b]
+
+
+def test_the_gravitational_constant_is_written_down_once(isa):
+    """NB_G lives in include/nbody.h and nowhere else: the kernels get it as a launch argument from the host, like the
+    reference's specialisation constant (reference src/lib/sim_gpu.c:54-72, src/shader/particle_cs.glsl:26).  No source
+    under nbody_amd/csrc may spell the value, and the device code of the two kernels that multiply by G must not hold
+    it as an instruction literal either."""
+    header = open(os.path.join(ROOT, "include", "nbody.h")).read()
+    value = float(re.search(r"^#define\s+NB_G\s+([0-9.eE+-]+)f\s*$", header, re.M).group(1))
+    import struct
+    literal = "0x%08x" % struct.unpack("<I", struct.pack("<f", value))[0]          # 0x41200000 for 10.0f
+    spelled = re.compile(r"(?<![\w.])%s(?:\.0*)?f?(?![\w.])" % re.escape(("%g" % value)))
+    csrc = os.path.join(ROOT, "nbody_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".h", ".c")) or name in ("galaxy.c", "bench_main.c"):
+            continue    # galaxy.c / bench_main.c: host code with unrelated tens (radii, warm-up steps); they use NB_G by name
+        text = re.sub(r"//[^\n]*|/\*.*?\*/", "", open(os.path.join(csrc, name)).read(), flags=re.S)
+        for m in spelled.finditer(text):
+            line = text[text.rfind("\n", 0, m.start()) + 1:text.find("\n", m.end())]
+            assert not re.search(r"f\b", m.group(0)) and "mul" not in line, f"{name}: `{line.strip()}` spells NB_G's value"
+    for src in ("kernels.hip", "pipeline.hip"):
+        assert "10.0f" not in open(os.path.join(csrc, src)).read(), src
+    assert "NB_G" in open(os.path.join(csrc, "pipeline.hip")).read()
+    fns = functions(isa)
+    users = {n: b for n, b in fns.items() if "make_gm_kernel" in n or "split_sources_kernel" in n}
+    assert len(users) == 2, sorted(fns)
+    for name, body in users.items():
+        assert any(ins.startswith("v_mul_f32") for ins in body), name
+        assert not any(literal in ins.lower() or re.search(r"\b10\.0\b", ins) for ins in body), (name, literal)

@@ -55,11 +55,14 @@ def test_bench_multi_rank_control_flow_dry_run(world):
         assert set(out[key]) == {"min", "max"}
     assert out["self_check"]["ranks_agree"] is True          # every rank generated the same initial conditions
     extra = out["extra_configs"]
-    assert [(e["overlap"], "N=65536" in e["workload"]) for e in extra] == [(1, True), (0, False), (1, False)]
-    assert all("N=131072" in e["workload"] for e in extra[1:])
+    # overlapped step, the chain captured as a hipGraph (north star), then config 5 plain and overlapped
+    assert [(e["overlap"], e["sharded_graph"], "N=65536" in e["workload"]) for e in extra] == \
+        [(1, 0, True), (0, 1, True), (0, 0, False), (1, 0, False)]
+    assert all("N=131072" in e["workload"] for e in extra[2:])
     for e in extra:
-        assert set(e) >= {"workload", "overlap", "steps", "ms_per_step", "steps_per_sec", "value", "unit",
+        assert set(e) >= {"workload", "overlap", "sharded_graph", "steps", "ms_per_step", "steps_per_sec", "value", "unit",
                           "kernel_ms_per_step", "comm_ms_per_step"}
+    assert "extras_aborted" not in out
     assert out["roofline"]["traffic"] is None and "traffic_note" in out["roofline"]
 
 

@@ -105,9 +105,13 @@ if "hbm_bytes_per_launch" in summary:
             if line.startswith("{") and '"roofline"' in line:
                 rec = json.loads(line)
                 launch = dict(rec["config"]["kernel"], passes=max(rec["roofline"]["launches"] // max(rec["steps"], 1), 1))
-    json.dump({"hbm_bytes_per_launch": summary["hbm_bytes_per_launch"], "source": f"profiles/{tag}_pmc_summary.json",
+    json.dump({"hbm_bytes_per_launch": summary["hbm_bytes_per_launch"], "fetch_bytes_raw": summary["fetch_bytes_raw"],
+               "write_bytes": summary["write_bytes"], "source": f"profiles/{tag}_pmc_summary.json",
                "n": 1 << 20, "kernel_sources_sha256": bench.kernel_sources_sha(), "launch": launch,
-               "note": "FETCH_SIZE*1024*2 (gfx950 correction) + WRITE_SIZE*1024, mean per step_kernel launch, N=2^20; "
-                       "run tools/summarize_profile.py on the same tree the profile was taken from"},
+               "note": "hbm_bytes_per_launch = FETCH_SIZE*1024*2 + WRITE_SIZE*1024, mean per step_kernel launch, N=2^20.  The x2 is "
+                       "MI355X_MICROARCH.md's gfx950 correction, calibrated on 16-B-per-lane coalesced streaming loads; this "
+                       "kernel loads 8-B float2 / 4-B float per lane plus 64-B scalar-cache lines (uncalibrated widths), so the "
+                       "corrected figure is an upper bound and fetch_bytes_raw + write_bytes a lower bound.  Run "
+                       "tools/summarize_profile.py on the same tree the profile was taken from"},
               open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
 print(text)
