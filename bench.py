@@ -317,6 +317,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="headline leg only: no repeats / alt_lds / extra_configs (1 GPU), no self_check / extra_configs (N GPUs)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="1 GPU: keep the repeats and the LDS-route leg but skip extra_configs (C1 / C2 / C3), so that a profiler's "
+                         "per-kernel averages hold the N = 2^20 launches only (tools/profile.sh)")
     ap.add_argument("--all-massive", action="store_true",
                     help="informational N^2 run: every particle is a source (not the BASELINE.json workload)")
     ap.add_argument("--dry-run", action="store_true",
@@ -682,7 +685,7 @@ def main():
                     "frac": lds_tf / PEAK_FP32_VECTOR_TFLOPS, "kernel": sim.launch_shape()}
         sim.close()
         sim = None
-        if not args.all_massive and args.n == N_PARTICLES:
+        if not args.all_massive and args.n == N_PARTICLES and not args.no_extra_configs:
             put("extra_configs", single_gpu_configs(nb))
     if sim is not None:
         sim.close()

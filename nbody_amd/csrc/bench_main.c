@@ -19,8 +19,10 @@
  *                  reference's single timed call; a row of a few hundred microseconds is at the mercy of one OS hiccup)
  * and more columns: interactions/s = N * mass_len * steps / time per backend, and for the GPU the share of the
  * fp32 roofline that is (14 flop per interaction, 157.3 TFLOP/s), then what the chip allows at THIS size:
- *   GPU floor = N * mass_len / 5.7e12 interactions/s  (the rate the step kernel sustains at N = 2^20, i.e. the
- *               instruction-mix bound of its 10 VALU instructions per interaction)
+ *   GPU floor = N * mass_len / R interactions/s       (R = the rate THIS run measures on THIS box at N = 100 000 before
+ *               the table starts -- a calibration world drawn from MakeGalaxiesSeeded, so libc's rand() stream and with
+ *               it the table's universes stay the reference's; boxes of the pool differ by up to 8 % on this kernel, so a
+ *               constant would silently shift %floor; printed on stderr; --floor-rate R overrides it)
  *             + kernels per step x 1.7 us              (dependent-launch floor inside a hipGraph on this box,
  *               profiles/r01_ubench6_launch_floor.txt; a step is 1 kernel, or 2 when the sources are split)
  *   %floor    = floor / measured: how close the step is to that bound.  Below N ~ 50 000 a launch cannot fill the
@@ -38,7 +40,7 @@
 #include <nbody.h>
 #include <nbody_hip.h>
 
-#define LARGE_N_RATE 5.7e12       /* interactions/s of the step kernel at N = 2^20 (bench.py, profiles/r02_bench.json) */
+#define CALIBRATION_N 100000u     /* the last row of the reference's table (bench.c:38): the large-N rate is measured there */
 #define LAUNCH_FLOOR_US 1.7       /* per dependent kernel inside a hipGraph (profiles/r01_ubench6_launch_floor.txt) */
 
 typedef void (*UpdateFn)(World *, float, uint32_t);
@@ -71,6 +73,24 @@ static uint32_t count_massive(const Particle *ps, uint32_t n) {
     return m;
 }
 
+/* interactions/s the step kernel sustains on this box once a launch fills the chip: N = 100 000, fastest of 3 timed
+ * 100-step calls, the per-kernel launch floor taken out so that the floor formula does not count it twice */
+static double measure_large_n_rate(void) {
+    Particle *ps = MakeGalaxiesSeeded(CALIBRATION_N, 2, 0x9e3779b97f4a7c15ull);
+    const uint32_t m = count_massive(ps, CALIBRATION_N);
+    World *w = CreateWorld(ps, CALIBRATION_N);
+    const double per_step = time_backend(w, UpdateWorld_GPU, 0.01f, 200, 100, 3);
+    DestroyWorld(w);
+    free(ps);
+    int k = 0, wv = 0, split = 1;
+    uint32_t groups = 0;
+    nb_hip_plan_launch(CALIBRATION_N, m, 256, &k, &wv, &split, &groups);
+    const double kernels = split > 1 ? 2.0 : 1.0;
+    double busy = per_step - kernels * LAUNCH_FLOOR_US * 1e-6;
+    if (busy <= 0.0) busy = per_step;
+    return (double)CALIBRATION_N * (double)m / busy;
+}
+
 static const uint32_t REFERENCE_SIZES[] = {250, 500, 800, 1200, 2000, 4000, 10000, 20000, 50000, 100000};
 
 int main(int argc, char **argv) {
@@ -81,6 +101,7 @@ int main(int argc, char **argv) {
     unsigned seed = 11037;
     bool own_rng = false;
     float dt = 1.f;
+    double floor_rate = 0.0; /* 0: measure it */
 
     for (int a = 1; a < argc; a++) {
         const char *arg = argv[a];
@@ -103,12 +124,14 @@ int main(int argc, char **argv) {
             seed = (unsigned)strtoul(val, NULL, 0), a++;
         } else if (!strcmp(arg, "--repeats") && val) {
             repeats = (uint32_t)strtoul(val, NULL, 0), a++;
+        } else if (!strcmp(arg, "--floor-rate") && val) {
+            floor_rate = strtod(val, NULL), a++;
         } else if (!strcmp(arg, "--own-rng")) {
             own_rng = true;
         } else {
             fprintf(stderr,
                     "usage: %s [--cpu|--gpu] [--n N]... [--steps K] [--warmup W] [--dt DT] [--galaxies G] [--seed S]"
-                    " [--own-rng] [--repeats R]\n",
+                    " [--own-rng] [--repeats R] [--floor-rate INT_PER_S]\n",
                     argv[0]);
             return 2;
         }
@@ -119,6 +142,11 @@ int main(int argc, char **argv) {
     }
     if (steps == 0) steps = 1;
     if (repeats == 0) repeats = 1;
+
+    if (use_gpu && floor_rate <= 0.0) {
+        floor_rate = measure_large_n_rate();
+        fprintf(stderr, "nbody-bench: floor rate %.3e interactions/s (measured at N = %u on this box)\n", floor_rate, CALIBRATION_N);
+    }
 
     srand(seed); /* one seed for the whole table, as the reference */
 
@@ -155,11 +183,11 @@ int main(int argc, char **argv) {
             int k = 0, wv = 0, split = 1;
             uint32_t groups = 0;
             const uint32_t m = count_massive(ps, n);
-            /* passes: one launch per <= 3 MiB of (x, y, G*m) sources (pipeline.hip passes_for) */
+            /* passes: one launch per <= 3 MiB of (x, y, G*m) sources (step_chain.hip passes_for) */
             const uint32_t passes = m ? (uint32_t)(((uint64_t)m * 12 + (3u << 20) - 1) / (3u << 20)) : 1;
             nb_hip_plan_launch(n, (m + passes - 1) / passes, 256, &k, &wv, &split, &groups);
             const double kernels = (double)passes * (split > 1 ? 2.0 : 1.0);
-            const double floor_us = pairs / LARGE_N_RATE * 1e6 + kernels * LAUNCH_FLOOR_US;
+            const double floor_us = pairs / floor_rate * 1e6 + kernels * LAUNCH_FLOOR_US;
             printf("\t%11.3e\t%9.1f\t%8.2f\t%8.2f\t%9.1f", pairs / gpu_s, pairs / gpu_s * 14.0 / 157.3e12 * 100.0, gpu_s * 1e6,
                    floor_us, floor_us / (gpu_s * 1e6) * 100.0);
         }

@@ -1023,8 +1023,11 @@ def test_bench_under_torchrun_with_one_forced_sharded_rank(mode):
     if mode == "plain":
         assert out["comm_ms_per_step"]["max"] > 0 and out["kernel_ms_per_step"]["max"] > 0
     extra = out["extra_configs"]
-    assert [e["overlap"] for e in extra] == [1, 0, 1] and all(e["value"] > 1e11 for e in extra)
-    assert all(e["comm_ms_per_step"]["max"] > 0 for e in extra if e["overlap"] == 1 or mode == "plain")
+    # overlapped step; the {kernel, ncclAllGather} x K chain captured as a hipGraph and replayed (north star); config 5 x 2
+    assert [(e["overlap"], e["sharded_graph"]) for e in extra] == [(1, 0), (0, 1), (0, 0), (1, 0)]
+    assert all(e["value"] > 1e11 for e in extra) and "extras_aborted" not in out
+    assert extra[1]["graph_stats"]["cached"] >= 1        # RCCL inside stream capture, instantiated and replayed
+    assert all(e["comm_ms_per_step"]["max"] > 0 for e in extra if not e["sharded_graph"] and (e["overlap"] == 1 or mode == "plain"))
 
 
 # ---------------------------------------------------------------------------------------------------------------

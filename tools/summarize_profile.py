@@ -17,7 +17,7 @@ lines = []
 stats = glob.glob(os.path.join(PROF, "stats", "*", "*_kernel_stats.csv"))
 step_avg_ns = None
 if stats:
-    lines.append("== rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 2 ==")
+    lines.append("== rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extra-configs --steps 10 --warmup 2 ==")
     for r in csv.DictReader(open(stats[0])):
         lines.append(f"{r['Name'][:90]:90s} calls={r['Calls']:>4s} avg_ns={float(r['AverageNs']):14.0f} total_ns={r['TotalDurationNs']:>14s} pct={float(r['Percentage']):7.3f}")
         if "step_kernel" in r["Name"] and step_avg_ns is None:   # rows are sorted by total time: the headline variant first
@@ -28,9 +28,19 @@ if stats:
     if tr:
         rows = [r for r in csv.DictReader(open(tr[0])) if "step_kernel" in r["Kernel_Name"]]
         if rows:
-            r = rows[0]
-            lines.append(f"step kernel dispatch: grid={r['Grid_Size_X']} wg={r['Workgroup_Size_X']} LDS={r['LDS_Block_Size']} "
-                         f"VGPR={r['VGPR_Count']} SGPR={r['SGPR_Count']} scratch={r['Scratch_Size']}")
+            # bench.py's extra_configs (C2 / C3) launch the same template instantiations at smaller sizes: the figure that must
+            # agree with roofline.kernel_ms_per_launch is the mean over the HEADLINE dispatches only -- the most frequent kernel
+            # name at its largest grid (N = 2^20)
+            top = collections.Counter(r["Kernel_Name"] for r in rows).most_common(1)[0][0]
+            big = max(int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) for r in rows if r["Kernel_Name"] == top)
+            head = [r for r in rows if r["Kernel_Name"] == top and int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) == big]
+            durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in head]
+            step_avg_ns = sum(durs) / len(durs)
+            r = head[0]
+            lines.append(f"headline step kernel {top}: {len(head)} dispatches of grid={r['Grid_Size_X']}x{r.get('Grid_Size_Y', 1)} "
+                         f"wg={r['Workgroup_Size_X']} LDS={r['LDS_Block_Size']} VGPR={r['VGPR_Count']} SGPR={r['SGPR_Count']} "
+                         f"scratch={r['Scratch_Size']}: mean {step_avg_ns:.0f} ns, min {min(durs)} ns, max {max(durs)} ns "
+                         f"(the per-name rows above also hold the smaller launches of extra_configs C2 / C3)")
 
 # bench.py also times the LDS-tile route (roofline.alt_lds): the counters below are those of the HEADLINE variant only,
 # i.e. of the step_kernel instantiation with the most launches
