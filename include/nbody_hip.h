@@ -168,6 +168,12 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
  *               with plain launches for the remainder; on larger worlds a chain length runs as plain launches the first
  *               time it is asked for and as a cached hipGraph from the second time on (a replay saves nothing there).
  *               The step size is never baked into a chain: kernels read it from device memory.
+ *   "fused_chain"  worlds that fit ONE 1024-thread workgroup (N <= 512) can run a whole n-step call inside one launch:
+ *               positions in LDS, two workgroup barriers per step, no kernel boundary (1.6-1.8 us each, more than such a
+ *               step's arithmetic).  2 (default) = auto: calls of 2+ steps while N x M <= 4e4 (about N <= 290: beyond that one
+ *               compute unit is slower than per-step launches over the whole chip) and the launch shape is on auto; 1 =
+ *               whenever the world fits; 0 = never.  Same bits as per-step launches with k = 2, w = 16 / tiles, split = 1,
+ *               unit = 8 (tiles = 1, 2, 4 for N <= 128, 256, 512); nb_hip_launch_shape reports that shape
  *   "readback"  when the device state reaches the host array named by nb_hip_note_host_array: 0 = only when
  *               GetSimulationData asks (merge kernel + D2H copy + wait), 1 = at the end of every blocking
  *               PerformSimUpdate (the merge kernel is appended to the update's own submission and stores straight into
@@ -187,6 +193,9 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
  * Returns the previous value; aborts on an unknown key or value.
  */
 int nb_hip_configure(SimPipeline *sim, const char *key, int value);
+
+/* Steps of the last PerformSimUpdate / nb_hip_step_async that ran inside one-workgroup chain launches ("fused_chain"). */
+uint32_t nb_hip_last_fused_steps(const SimPipeline *sim);
 
 /* What the last step launch actually used (after "auto"): fills k, w, variant, split, workgroups. */
 void nb_hip_launch_shape(const SimPipeline *sim, int *k, int *w, int *variant, int *split, uint32_t *workgroups);

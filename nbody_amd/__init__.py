@@ -66,6 +66,7 @@ HIP_API = {
     "nb_hip_graph_stats": (C.c_uint32, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "nb_hip_runtime_version": (C.c_int, []),
     "nb_hip_launch_unit": (C.c_int, [C.c_void_p]),
+    "nb_hip_last_fused_steps": (C.c_uint32, [C.c_void_p]),
     "nb_hip_note_host_array": (None, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "nb_hip_configure": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "nb_hip_launch_shape": (None, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
@@ -271,6 +272,10 @@ class SimPipeline:
         uploads = C.c_uint32(0)
         cached = hip_lib().nb_hip_graph_stats(self._h, C.byref(uploads))
         return {"cached": int(cached), "dt_uploads": int(uploads.value)}
+
+    def fused_steps(self):
+        """steps of the last update that ran inside one-workgroup chain launches (knob fused_chain)."""
+        return int(hip_lib().nb_hip_last_fused_steps(self._h))
 
     def configure(self, **knobs):
         for k, v in knobs.items():

@@ -59,6 +59,26 @@ struct StepParams {
     uint32_t unit;
 };
 
+// A whole n-step chain of a world that fits ONE workgroup, run inside one launch (chain_kernel): positions ping-pong in
+// LDS, velocities and radii stay in registers, two workgroup barriers per step and no kernel boundary (1.6-1.8 us each
+// on this chip, more than such a step's arithmetic).  Sixteen waves: `tiles` receiver tiles of 64 * K receivers, 16 / tiles
+// waves per tile, each over a 1/W slice of the sources in 8-source granules -- the summation order of the per-step
+// kernel launched with k = K, w = 16 / tiles, split = 1, unit = 8, so the two paths give the same bits.
+struct ChainParams {
+    float2 *pos;          // in: state before the chain; out: state after it (updated in place)
+    float2 *vel;          // in / out
+    float2 *acc;          // out: the last step's sums (Particle.acc is observable)
+    const float *radius;
+    const float *src_gm;  // G*m of the sources = the first n_src receivers (massive-first order)
+    uint32_t n_recv;      // receivers, <= 128 * tiles
+    uint32_t n_src;       // sources, <= n_recv
+    uint32_t steps;       // steps to run, >= 1
+    uint32_t tiles;       // 1, 2 or 4
+    const float *dt;      // step size in device memory, as for the per-step kernels
+};
+
+constexpr uint32_t CHAIN_MAX_RECV = 512;   // 4 tiles of 128 receivers (K = 2)
+
 struct LaunchShape {
     int k;        // receivers per lane: 1, 2 (4 in tuning builds)
     int w;        // waves per workgroup = source slices: 1, 4, 8, 16 (2 in tuning builds)
@@ -80,6 +100,10 @@ dim3 step_block(LaunchShape s);
 const void *finish_kernel_fn();
 dim3 finish_grid(uint32_t n_recv);
 dim3 finish_block();
+
+// the one-workgroup chain: 1024 threads, one block; tiles from chain_tiles(n_recv) (0: the world does not fit)
+uint32_t chain_tiles(uint32_t n_recv);
+void launch_chain(hipStream_t st, const ChainParams &p);
 
 // AoS <-> SoA converters (reference Particle layout, include/nbody.h).
 // split: aos[first .. first+count) -> soa slots [slot0 .. slot0+count)

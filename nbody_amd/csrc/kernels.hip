@@ -475,6 +475,114 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
     }
 }
 
+// ---- the one-workgroup chain -------------------------------------------------------------------------------------
+//
+// Worlds of a few hundred particles are bound by the kernel boundary, not by arithmetic: at N = 250 a step is 30 000
+// interactions -- 1.3 us on ONE compute unit -- while a dependent launch costs 1.6-1.8 us before its kernel has
+// loaded anything (profiles/r01_ubench6_launch_floor.txt).  So such a world runs its whole n-step chain inside one
+// launch of one 1024-thread workgroup: positions ping-pong between two LDS arrays, G*m sits in LDS, radii and
+// velocities stay in registers, and a step is {force loop from LDS, partial sums to LDS, barrier, sum + integrate,
+// barrier}.  Nothing crosses the chip per step.  (More than one workgroup would need an in-kernel all-gather of the
+// positions per step: 2.4 us for 8 KB between 32 CUs, MI355X_MICROARCH.md price list "allgather" -- dearer than the
+// kernel boundary it would replace, which is why the path stops at one workgroup.)
+//
+// Bit-compatible with the per-step kernel by construction: same interaction statements, same slicing arithmetic
+// (granule 8, W = 16 / tiles slices per receiver tile), same block closes, same reduction order, same integrator
+// roundings -- tests/test_gpu_parity.py holds it to plain launches of k = 2, w = 16 / tiles, split = 1, unit = 8.
+constexpr uint32_t CHAIN_K = 2;
+
+__global__ __launch_bounds__(1024) void chain_kernel(const ChainParams p) {
+    constexpr int K = CHAIN_K;
+    __shared__ __attribute__((aligned(16))) float spos[2][2 * CHAIN_MAX_RECV];  // (x, y) interleaved, ping-pong
+    __shared__ __attribute__((aligned(16))) float sgm[CHAIN_MAX_RECV];
+    __shared__ float2 partial[16][WAVE * K];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (WAVE - 1);
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t W = 16u / p.tiles;              // waves (= source slices) per receiver tile
+    const uint32_t tile = wid / W, slice = wid % W;
+    const uint32_t tile_base = tile * (WAVE * K);
+    const float dt = *p.dt;
+
+    // ---- load: every position and G*m into LDS, this lane's radii and (integrating threads) velocity into registers
+    for (uint32_t i = tid; i < p.n_recv; i += 1024) {
+        const float2 q = p.pos[i];
+        spos[0][2 * i] = q.x;
+        spos[0][2 * i + 1] = q.y;
+        if (i < p.n_src) sgm[i] = p.src_gm[i];
+    }
+    Receivers<K> R;
+    uint32_t ridx[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        uint32_t i = tile_base + k * WAVE + lane;
+        i = i < p.n_recv ? i : p.n_recv - 1;  // tail lanes redo the last receiver; they never store
+        ridx[k] = i;
+        R.r[k] = p.radius[i];
+    }
+    // the thread that integrates receiver slot `local` of its tile (the per-step kernel's `slot = tid` thread)
+    const uint32_t local = tid - tile * W * WAVE;
+    const uint32_t mine = tile_base + local;
+    const bool integrates = local < WAVE * K && mine < p.n_recv;
+    float2 v = make_float2(0.f, 0.f), a = make_float2(0.f, 0.f);
+    if (integrates) v = p.vel[mine];
+
+    // this wave's slice of the sources: whole 8-source granules, exactly StepParams::unit = 8 with split = 1
+    const uint32_t nunits = (p.n_src + 7u) / 8u;
+    const uint32_t per_wave = (nunits + W - 1) / W;
+    const uint32_t u_lo = min(slice * per_wave, nunits);
+    const uint32_t u_hi = min(u_lo + per_wave, nunits);
+    const uint32_t v_lo = u_lo * 8u;
+    const uint32_t v_hi = min(u_hi * 8u, p.n_src);
+    __syncthreads();
+
+    int cur = 0;
+    for (uint32_t step = 0; step < p.steps; step++) {
+        const float *S = spos[cur];
+#pragma unroll
+        for (int k = 0; k < K; k++) R.p[k] = f2v{S[2 * ridx[k]], S[2 * ridx[k] + 1]};
+        R.clear();
+        uint32_t j = v_lo;
+        const uint32_t groups = (v_hi - v_lo) / 8u;
+        for (uint32_t g = 0; g < groups; g++, j += 8) {
+            const v16f P = *reinterpret_cast<const v16f *>(&S[2 * j]);   // broadcast reads: every lane the same address
+            const v8f G = *reinterpret_cast<const v8f *>(&sgm[j]);
+            interact8<K, false>(R, P, G);
+            if ((g & (8u * CLOSE_EVERY - 1)) == 8u * CLOSE_EVERY - 1) R.close_chunk();   // every 256 sources of the slice
+        }
+        for (; j < v_hi; j++) interact<K, false>(R, f2v{S[2 * j], S[2 * j + 1]}, sgm[j]);
+        if ((v_hi - v_lo) & (CHUNK * CLOSE_EVERY - 1)) R.close_chunk();                   // a short last block
+#pragma unroll
+        for (int k = 0; k < K; k++) partial[wid][k * WAVE + lane] = make_float2(R.s[k].x, R.s[k].y);
+        __syncthreads();
+        if (integrates) {
+            float sx = 0.0f, sy = 0.0f;
+            for (uint32_t s = 0; s < W; s++) {   // the tile's slices in wave order: deterministic, = the per-step kernel
+                const float2 t = partial[tile * W + s][local];
+                sx = __fadd_rn(sx, t.x);
+                sy = __fadd_rn(sy, t.y);
+            }
+            a = make_float2(sx, sy);
+            // semi-implicit Euler with the reference's roundings (finish_receiver): vel += acc*dt; pos += vel*dt
+            v.x = __fadd_rn(v.x, __fmul_rn(a.x, dt));
+            v.y = __fadd_rn(v.y, __fmul_rn(a.y, dt));
+            float qx = S[2 * mine], qy = S[2 * mine + 1];
+            qx = __fadd_rn(qx, __fmul_rn(v.x, dt));
+            qy = __fadd_rn(qy, __fmul_rn(v.y, dt));
+            spos[cur ^ 1][2 * mine] = qx;
+            spos[cur ^ 1][2 * mine + 1] = qy;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (integrates) {
+        p.pos[mine] = make_float2(spos[cur][2 * mine], spos[cur][2 * mine + 1]);
+        p.vel[mine] = v;
+        p.acc[mine] = a;
+    }
+}
+
 // ---- AoS <-> SoA ----------------------------------------------------------------------------------------
 
 struct alignas(16) ParticleRec {  // == Particle (include/nbody.h): pos vel | acc mass radius
@@ -693,6 +801,16 @@ const void *finish_kernel_fn() { return reinterpret_cast<const void *>(&finish_k
 dim3 finish_grid(uint32_t n_recv) { return dim3((n_recv + 255u) / 256u); }
 dim3 finish_block() { return dim3(256); }
 dim3 step_block(LaunchShape s) { return dim3(WAVE * s.w); }
+
+uint32_t chain_tiles(uint32_t n_recv) {
+    for (uint32_t t = 1; t <= 4; t *= 2)
+        if (n_recv <= t * WAVE * CHAIN_K) return t;
+    return 0;
+}
+
+void launch_chain(hipStream_t st, const ChainParams &p) {
+    hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(1024), 0, st, p);
+}
 
 void launch_split(hipStream_t st, const void *aos, uint32_t first, uint32_t count, float2 *pos, float2 *vel, float2 *acc,
                   float *radius, float *mass, uint32_t slot0) {

@@ -176,6 +176,8 @@ SimPipeline *CreateSimPipeline(WorldData data) {
     if (zc) s->zero_copy_upload = atoi(zc) ? 1 : 0;
     const char *tm = getenv("NB_HIP_TIMING");
     if (tm) s->timing = atoi(tm) ? 1 : 0;
+    const char *fc = getenv("NB_HIP_FUSED_CHAIN");
+    if (fc) s->fused_chain = atoi(fc) < 0 || atoi(fc) > 2 ? 2 : atoi(fc);
     const char *gr = getenv("NB_HIP_GRAPH");
     if (gr) s->use_graph = atoi(gr) < 0 || atoi(gr) > 2 ? 2 : atoi(gr);
     return s;
@@ -462,6 +464,11 @@ uint32_t nb_hip_graph_stats(const SimPipeline *s, uint32_t *dt_uploads) {
     return (uint32_t)s->graphs.size();
 }
 
+uint32_t nb_hip_last_fused_steps(const SimPipeline *s) {
+    NB_ASSERT(s != nullptr, "NULL pipeline");
+    return s->fused_steps;
+}
+
 int nb_hip_launch_unit(const SimPipeline *s) {
     NB_ASSERT(s != nullptr, "NULL pipeline");
     return s->last_shape.unit;
@@ -505,6 +512,10 @@ int nb_hip_configure(SimPipeline *s, const char *key, int value) {
         NB_ASSERT(value >= 0 && value <= 2, "graph must be 0 (never), 1 (always) or 2 (from the second use), got %d", value);
         old = s->use_graph;
         s->use_graph = value;
+    } else if (!strcmp(key, "fused_chain")) {
+        NB_ASSERT(value >= 0 && value <= 2, "fused_chain must be 0 (never), 1 (whenever the world fits one workgroup) or 2 (auto), got %d", value);
+        old = s->fused_chain;
+        s->fused_chain = value;
     } else if (!strcmp(key, "passes")) {
         NB_ASSERT(value >= 0 && value <= 64, "passes must be 0 (auto) .. 64, got %d", value);
         old = s->want_passes;

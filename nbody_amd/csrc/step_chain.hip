@@ -257,12 +257,55 @@ StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchS
 // reference's nbody-bench -- ONE 100-step call per world (bench.c:30-33) -- runs 96 of its 100 steps at the replay rate.
 constexpr double CANON_MAX_PAIRS = 6.0e7;  // N x M up to which a replay still pays (N ~ 11 000 with galaxy.h ICs)
 
+// A world that fits one workgroup runs its chains inside ONE launch (kernels.hip chain_kernel).  "fused_chain" = 2
+// (auto): only while a step is cheaper on one compute unit than the kernel boundary it saves -- N x M <= 4e4, about
+// N <= 290 with galaxy.h's half-massless universes (one CU needs ~1.3 us for the 3e4 interactions of N = 250, ~5 us
+// for the 1.2e5 of N = 500, where the per-step launches take 4.0: profiles/r03_fused_chain.txt) -- for calls of two
+// steps or more, and only with the launch shape left on auto (an explicit k / w / split / unit / passes asks for the
+// per-step kernel).  1 = whenever the world fits (N <= 512), whatever the other knobs say; 0 = never.
+constexpr double CHAIN_MAX_PAIRS = 4.0e4;
+constexpr uint32_t CHAIN_MAX_STEPS_PER_LAUNCH = 1u << 16;
+
+bool wants_fused_chain(const SimPipeline *s) {
+    if (s->sharded || s->fused_chain == 0 || s->n_real == 0 || nb::chain_tiles(s->n_real) == 0) return false;
+    if (s->fused_chain == 1) return true;
+    const bool shape_on_auto = s->want_k == 0 && s->want_w == 0 && s->want_split == 0 && s->want_unit == 0 && s->want_passes == 0;
+    return shape_on_auto && (double)s->n_real * (double)(s->n_src ? s->n_src : 1) <= CHAIN_MAX_PAIRS;
+}
+
+void enqueue_fused(SimPipeline *s, uint32_t n) {
+    nb::ChainParams p;
+    memset(&p, 0, sizeof p);
+    p.pos = s->pos[s->cur];   // updated in place: the ping-pong phase does not move
+    p.vel = s->vel;
+    p.acc = s->acc;
+    p.radius = s->radius;
+    p.src_gm = s->src_gm;
+    p.n_recv = s->n_real;
+    p.n_src = s->n_src;
+    p.tiles = nb::chain_tiles(s->n_real);
+    p.dt = s->dt_dev;
+    for (uint32_t left = n; left > 0;) {
+        p.steps = left > CHAIN_MAX_STEPS_PER_LAUNCH ? CHAIN_MAX_STEPS_PER_LAUNCH : left;
+        nb::launch_chain(s->stream, p);
+        left -= p.steps;
+    }
+    s->fused_steps = n;
+    s->last_shape = {2, (int)(16u / p.tiles), nb::VARIANT_LDS, 1, 8};   // the per-step shape it is bit-equal to
+    s->last_groups = 1;
+}
+
 bool wants_canonical(const SimPipeline *s) {
+    if (s->fused_chain == 2 && wants_fused_chain(s)) return false;   // its chains never reach the graph path
     return !s->sharded && s->use_graph == 2 && s->n_real > 0 &&
            (double)s->n_real * (double)(s->n_src ? s->n_src : 1) <= CANON_MAX_PAIRS;
 }
 
 void enqueue_single(SimPipeline *s, uint32_t n, float dt) {
+    if (n >= 2 && wants_fused_chain(s)) {
+        enqueue_fused(s, n);
+        return;
+    }
     const nb::LaunchShape sh = resolve_shape(s);
     if (!s->use_graph || n == 1 || (s->use_graph == 2 && n < GRAPH_AUTO_MIN_CHAIN)) {
         for (uint32_t i = 0; i < n; i++) {
@@ -480,6 +523,7 @@ void enqueue_steps(SimPipeline *s, uint32_t n, float dt) {
     s->kernel_iv.clear();
     s->comm_iv.clear();
     s->detail_steps = 0;
+    s->fused_steps = 0;
     s->host_current = false;
     upload_dt(s, dt);
     if (s->timing) ASSERT_HIP(hipEventRecord(s->ev_begin, s->stream), "record begin");
@@ -490,6 +534,7 @@ void enqueue_steps(SimPipeline *s, uint32_t n, float dt) {
     if (s->timing) ASSERT_HIP(hipEventRecord(s->ev_end, s->stream), "record end");
     s->timed = s->timing != 0;
     s->timed_launches = (s->sharded && s->overlap) ? 2 * n : n * passes_for(s, whole_step(s, s->cur, dt));
+    if (s->fused_steps) s->timed_launches = (n + CHAIN_MAX_STEPS_PER_LAUNCH - 1) / CHAIN_MAX_STEPS_PER_LAUNCH;
     s->timed_finish_launches = s->last_shape.split > 1 ? s->timed_launches : 0;
     s->data.dt = dt;
 }

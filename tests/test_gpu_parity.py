@@ -360,6 +360,108 @@ def test_async_steps_then_sync(golden):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# the one-workgroup chain (knob "fused_chain"): a whole n-step call inside ONE launch, positions in LDS
+# ---------------------------------------------------------------------------------------------------------------
+
+def matched_shape(n):
+    """The per-step launch shape whose summation order the one-workgroup chain reproduces."""
+    tiles = 1 if n <= 128 else 2 if n <= 256 else 4
+    return dict(k=2, w=16 // tiles, split=1, unit=8)
+
+
+@pytest.mark.parametrize("n_steps", [2, 3, 7, 64, 65, 130])
+@pytest.mark.parametrize("n", [100, 250, 333, 512])
+def test_fused_chain_equals_plain_launches(n, n_steps):
+    """n steps inside one launch == n per-step launches of the matching shape (k = 2, w = 16 / tiles, split = 1,
+    unit = 8), bit for bit: same interaction statements, same source slices, same reduction order, same integrator
+    roundings; only the kernel boundaries are gone."""
+    part, m = bench_universe(n)[1:] if n >= 200 else synth(n, 0.5, seed=n)   # MakeGalaxies needs 100 per galaxy
+    sim = nb.SimPipeline(n, m)
+    sim.configure(fused_chain=1)
+    sim.set_data(part)
+    sim.update(n_steps, 0.01)
+    assert sim.fused_steps() == n_steps and sim.last_step_ms()[1] == 1          # ONE launch
+    shape = sim.launch_shape()
+    assert {key: shape[key] for key in ("k", "w", "split", "unit")} == matched_shape(n) and shape["workgroups"] == 1
+    got = sim.get_data()
+    sim.close()
+    want = run(part, m, n_steps, 0.01, fused_chain=0, graph=0, **matched_shape(n))
+    assert got.tobytes() == want.tobytes()
+    assert got.tobytes() == run(part, m, n_steps, 0.01, fused_chain=0, graph=1, variant=0, **matched_shape(n)).tobytes()
+
+
+def test_fused_chain_auto_policy_and_split_calls():
+    """Auto: calls of 2+ steps on worlds with N x M <= 4e4 (the reference harness' N = 250 row) run fused, single steps
+    and larger worlds do not; a new dt reaches the chain through device memory like any other step; and a sequence of
+    fused calls equals one long fused call."""
+    _, part, m = bench_universe(250)
+    sim = nb.SimPipeline(250, m)
+    sim.set_data(part)
+    sim.update(1, 0.01)
+    assert sim.fused_steps() == 0                       # one step: nothing to fuse
+    sim.set_data(part)
+    for n_steps, dt in ((3, 0.01), (2, 0.005), (100, 0.01), (5, 0.0025)):
+        sim.update(n_steps, dt)
+        assert sim.fused_steps() == n_steps
+    got = sim.get_data()
+    assert sim.graph_stats()["cached"] == 0 and sim.graph_stats()["dt_uploads"] == 4   # no hipGraph is ever built for it
+    sim.close()
+    ref = nb.SimPipeline(250, m)
+    ref.configure(fused_chain=0, graph=0, **matched_shape(250))
+    ref.set_data(part)
+    for n_steps, dt in ((3, 0.01), (2, 0.005), (100, 0.01), (5, 0.0025)):
+        ref.update(n_steps, dt)
+        assert ref.fused_steps() == 0
+    want = ref.get_data()
+    ref.close()
+    assert got.tobytes() == want.tobytes()
+    # explicit shape knobs ask for the per-step kernel; larger worlds stay on it
+    assert run(part, m, 4, 0.01, k=1, w=16).tobytes() == run(part, m, 4, 0.01, k=1, w=16, fused_chain=0).tobytes()
+    _, part333, m333 = bench_universe(333)
+    big = nb.SimPipeline(333, m333)
+    big.set_data(part333)
+    big.update(10, 0.01)
+    assert big.fused_steps() == 0
+    big.close()
+
+
+def test_fused_chain_against_the_reference_path():
+    """The fused chain is the default for the reference harness' smallest world: one step from the bench's N = 250
+    universe against float64 (through two fused steps with dt = 0: the second step's acc is the force at the unmoved
+    state), and ten steps against the reference's AVX stepper on the displacement metric."""
+    _, part, m = bench_universe(250)
+    still = run(part, m, 2, 0.0)                        # dt = 0: nothing moves, acc = the force field, twice
+    acc64, mag = ob.acc_f64(part, m)
+    assert np.all(np.abs(still[:, 4:6].astype(np.float64) - acc64) <= acc_bound(acc64, mag))
+    assert np.array_equal(still[:, 0:4], part[:, 0:4]) and np.array_equal(still[:, 6:8], part[:, 6:8])
+    want = ob.step(part, m, 0.01, 10, kind="avx")
+    sim = nb.SimPipeline(250, m)
+    sim.set_data(part)
+    sim.update(10, 0.01)
+    assert sim.fused_steps() == 10
+    got = sim.get_data()
+    sim.close()
+    assert rel_l2_pos(got, want) <= 1e-6 and rel_displacement(got, want, part) <= DISPLACEMENT_TOL
+    # the World surface takes the same path (nbody-bench's 100-step call)
+    ic = nb.make_galaxies(250, 2, seed=11037)
+    w = nb.World(ic)
+    w.update_gpu(0.01, 10)
+    assert w.particles().tobytes() == got.tobytes()
+    w.close()
+
+
+@pytest.mark.parametrize("n,frac", [(1, 1.0), (2, 0.5), (64, 1.0), (65, 0.3), (129, 0.02), (130, 1.0), (257, 0.5), (300, 0.0),
+                                    (511, 1.0), (512, 0.6)])
+def test_fused_chain_ragged_worlds(n, frac):
+    part, m = synth(n, frac, seed=7 * n)
+    got = run(part, m, 3, 0.02, fused_chain=1)
+    want = run(part, m, 3, 0.02, fused_chain=0, graph=0, **matched_shape(n))
+    assert got.tobytes() == want.tobytes()
+    if m:
+        check_one_step(run(part, m, 1, 0.02, fused_chain=0, **matched_shape(n)), part, m, 0.02)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # kernel properties: determinism, variants, linearity, edge shapes
 # ---------------------------------------------------------------------------------------------------------------
 
