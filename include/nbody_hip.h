@@ -170,7 +170,7 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
  *               The step size is never baked into a chain: kernels read it from device memory.
  *   "fused_chain"  worlds that fit ONE 1024-thread workgroup (N <= 512) can run a whole n-step call inside one launch:
  *               positions in LDS, two workgroup barriers per step, no kernel boundary (1.6-1.8 us each, more than such a
- *               step's arithmetic).  2 (default) = auto: calls of 2+ steps while N x M <= 4e4 (about N <= 290: beyond that one
+ *               step's arithmetic).  2 (default) = auto: calls of 2+ steps while N <= 256 and N x M <= 3.6e4 (beyond that one
  *               compute unit is slower than per-step launches over the whole chip) and the launch shape is on auto; 1 =
  *               whenever the world fits; 0 = never.  Same bits as per-step launches with k = 2, w = 16 / tiles, split = 1,
  *               unit = 8 (tiles = 1, 2, 4 for N <= 128, 256, 512); nb_hip_launch_shape reports that shape

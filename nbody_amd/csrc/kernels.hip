@@ -534,7 +534,9 @@ __global__ __launch_bounds__(1024) void chain_kernel(const ChainParams p) {
     const uint32_t u_lo = min(slice * per_wave, nunits);
     const uint32_t u_hi = min(u_lo + per_wave, nunits);
     const uint32_t v_lo = u_lo * 8u;
-    const uint32_t v_hi = min(u_hi * 8u, p.n_src);
+    // an empty slice past a ragged last granule would have v_hi < v_lo (7 granules over 16 waves, 50 sources: wave 7
+    // starts at 56): clamp, so that the unsigned lengths below are 0 there and the loops cannot run away
+    const uint32_t v_hi = max(min(u_hi * 8u, p.n_src), v_lo);
     __syncthreads();
 
     int cur = 0;

@@ -258,19 +258,21 @@ StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchS
 constexpr double CANON_MAX_PAIRS = 6.0e7;  // N x M up to which a replay still pays (N ~ 11 000 with galaxy.h ICs)
 
 // A world that fits one workgroup runs its chains inside ONE launch (kernels.hip chain_kernel).  "fused_chain" = 2
-// (auto): only while a step is cheaper on one compute unit than the kernel boundary it saves -- N x M <= 4e4, about
-// N <= 290 with galaxy.h's half-massless universes (one CU needs ~1.3 us for the 3e4 interactions of N = 250, ~5 us
-// for the 1.2e5 of N = 500, where the per-step launches take 4.0: profiles/r03_fused_chain.txt) -- for calls of two
-// steps or more, and only with the launch shape left on auto (an explicit k / w / split / unit / passes asks for the
+// (auto): only while a step is cheaper on one compute unit than the kernel boundary it saves -- N <= 256 (two receiver
+// tiles of eight waves each; with four tiles a wave's source slice is 2.5x longer) and N x M <= 3.6e4.  Measured
+// (profiles/r03_fused_chain.txt): 2.25 us per step at N = 200 / 250 against 3.1 as per-step launches, but 4.95 against
+// 3.4 at N = 300 and 7.6 against 3.7 at N = 512 -- one CU runs the interaction body at ~63 % of its issue rate with four
+// latency-bound waves per SIMD.  For calls of two steps or more, and only with the launch shape left on auto (an explicit k / w / split / unit / passes asks for the
 // per-step kernel).  1 = whenever the world fits (N <= 512), whatever the other knobs say; 0 = never.
-constexpr double CHAIN_MAX_PAIRS = 4.0e4;
+constexpr double CHAIN_MAX_PAIRS = 3.6e4;
+constexpr uint32_t CHAIN_AUTO_MAX_RECV = 256;
 constexpr uint32_t CHAIN_MAX_STEPS_PER_LAUNCH = 1u << 16;
 
 bool wants_fused_chain(const SimPipeline *s) {
     if (s->sharded || s->fused_chain == 0 || s->n_real == 0 || nb::chain_tiles(s->n_real) == 0) return false;
     if (s->fused_chain == 1) return true;
     const bool shape_on_auto = s->want_k == 0 && s->want_w == 0 && s->want_split == 0 && s->want_unit == 0 && s->want_passes == 0;
-    return shape_on_auto && (double)s->n_real * (double)(s->n_src ? s->n_src : 1) <= CHAIN_MAX_PAIRS;
+    return shape_on_auto && s->n_real <= CHAIN_AUTO_MAX_RECV && (double)s->n_real * (double)(s->n_src ? s->n_src : 1) <= CHAIN_MAX_PAIRS;
 }
 
 void enqueue_fused(SimPipeline *s, uint32_t n) {

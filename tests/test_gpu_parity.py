@@ -387,11 +387,11 @@ def test_fused_chain_equals_plain_launches(n, n_steps):
     sim.close()
     want = run(part, m, n_steps, 0.01, fused_chain=0, graph=0, **matched_shape(n))
     assert got.tobytes() == want.tobytes()
-    assert got.tobytes() == run(part, m, n_steps, 0.01, fused_chain=0, graph=1, variant=0, **matched_shape(n)).tobytes()
+    assert got.tobytes() == run(part, m, n_steps, 0.01, fused_chain=0, graph=1, **matched_shape(n)).tobytes()
 
 
 def test_fused_chain_auto_policy_and_split_calls():
-    """Auto: calls of 2+ steps on worlds with N x M <= 4e4 (the reference harness' N = 250 row) run fused, single steps
+    """Auto: calls of 2+ steps on worlds with N <= 256 and N x M <= 3.6e4 (the reference harness' N = 250 row) run fused, single steps
     and larger worlds do not; a new dt reaches the chain through device memory like any other step; and a sequence of
     fused calls equals one long fused call."""
     _, part, m = bench_universe(250)
