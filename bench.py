@@ -264,6 +264,42 @@ def algorithmic_bytes_per_launch(n, m, passes):
 
 # ---- deadline guard of the optional legs --------------------------------------------------------------------------------
 
+class LastGasp:
+    """The optional legs can also die the hard way: the library's error convention is the reference's -- print and abort()
+    (src/lib/util.h:17-29) -- and RCCL inside stream capture with several ranks has never run anywhere.  A fatal signal
+    raised inside a C call never reaches a Python-level handler, so rank 0 registers a C-level one (a ctypes callback handed
+    to libc's signal()) for SIGABRT / SIGSEGV / SIGBUS / SIGFPE while optional legs run: it writes the line prepared when
+    the current leg was armed -- headline + self-check + the legs finished so far + "extras_aborted" -- and leaves with
+    os._exit(6).  One write of bytes serialised beforehand; nothing else happens in signal context."""
+
+    SIGNALS = (6, 11, 7, 8)   # SIGABRT, SIGSEGV, SIGBUS, SIGFPE
+
+    def __init__(self, fd):
+        self.fd, self.line, self.done = fd, None, False
+        self._libc = C.CDLL(None, use_errno=True)
+        self._proto = C.CFUNCTYPE(None, C.c_int)
+        self._handler = self._proto(self._on_signal)   # must outlive the registration
+        self._libc.signal.restype = C.c_void_p
+        self._libc.signal.argtypes = [C.c_int, self._proto]
+
+    def arm(self, line_bytes):
+        first = self.line is None
+        self.line = line_bytes
+        if first:
+            for sig in self.SIGNALS:
+                self._libc.signal(sig, self._handler)
+
+    def disarm(self):
+        self.done = True
+
+    def _on_signal(self, sig):
+        if not self.done and self.line is not None:
+            self.done = True
+            os.write(self.fd, self.line)
+            os.write(2, f"[bench] fatal signal {sig} inside an optional leg; the line written holds what was in hand (exit 6)\n".encode())
+        os._exit(6)
+
+
 class LegGuard:
     """Host-side deadline around every optional leg.  The legs block inside C calls (ctypes releases the GIL), so a
     Python thread can watch the clock: on expiry rank 0 writes the JSON line with what is in hand plus
@@ -330,6 +366,9 @@ def main():
     ap.add_argument("--stall-leg", default=None,
                     help="rehearsal only (host transport): the all-gather callback never returns during this leg "
                          "(overlap | sharded_graph | config5), to exercise the deadline path")
+    ap.add_argument("--crash-leg", default=None,
+                    help="rehearsal only (host transport): rank 0 abort()s inside this leg's all-gather, to exercise the "
+                         "last-gasp line")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -398,6 +437,8 @@ def main():
             """In-place all-gather of host rows over gloo (rows[r] is filled on entry)."""
             if args.stall_leg and current_leg["name"] == args.stall_leg:
                 time.sleep(3600.0)   # rehearsal of a collective that never completes (--stall-leg)
+            if args.crash_leg and current_leg["name"] == args.crash_leg and r == 0:
+                os.abort()           # rehearsal of a leg that dies by the library's abort() convention (--crash-leg)
             if dist is None:
                 return
             mine = torch.from_numpy(rows[r].copy())
@@ -592,11 +633,15 @@ def main():
     # ---- optional legs ------------------------------------------------------------------------------------------
     if sharded and not args.no_extras:
         guard = LegGuard(rank, lambda leg: emit({"extras_aborted": leg}), args.leg_deadline_s) if not args.dry_run else None
+        gasp = LastGasp(json_fd) if (rank == 0 and not args.dry_run) else None
 
         def leg(name):
             current_leg["name"] = name
             if guard:
                 guard.arm(name)
+            if gasp:
+                with out_lock:
+                    gasp.arm((json.dumps(dict(out, extras_aborted=f"{name} (fatal signal)")) + "\n").encode())
 
         if args.dry_run:
             digest = hashlib.sha256(part.tobytes()).digest()
@@ -667,6 +712,8 @@ def main():
             sim5.close()
             if guard:
                 guard.disarm()
+            if gasp:
+                gasp.disarm()
     elif not sharded and not args.no_extras and not args.dry_run:
         # same K steps twice more (run-to-run spread), then the LDS-tile route of the north star on the same chain
         put("repeat_ms_per_step", [timed_leg(sim, args.steps, 0) / args.steps * 1e3 for _ in range(2)])

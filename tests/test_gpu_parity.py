@@ -1313,6 +1313,26 @@ def test_bench_line_survives_a_stuck_leg():
     assert "passed its deadline" in r.stderr
 
 
+def test_bench_line_survives_a_leg_that_aborts():
+    """... and not to an optional leg that dies by the library's own error convention (print + abort(), reference
+    src/lib/util.h:17-29) either: rank 0's C-level handler writes the line prepared when the leg was armed."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29745", os.path.join(nb.ROOT, "bench.py"), "--gpus", "2", "--transport", "host",
+           "--steps", "4", "--warmup", "1", "--particles", "65536", "--extra-particles", "131072", "--crash-leg", "config5"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=nb.ROOT)
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(lines[0])
+    assert out["extras_aborted"] == "config5 (fatal signal)" and out["value"] > 1e10
+    assert out["self_check"]["ranks_agree"] is True
+    # the legs that had finished before the crash are on the line: the overlapped step and the (skipped) captured chain
+    assert [(e["overlap"], e["sharded_graph"]) for e in out["extra_configs"]] == [(1, 0), (0, 1)]
+    assert "fatal signal 6" in r.stderr
+
+
 def test_host_transport_callback_that_raises_ends_the_process(golden, tmp_path):
     """A Python exception inside the caller-supplied all-gather must not escape into ctypes (it would be swallowed
     and the pipeline would step on stale peer slots): the thunk prints the traceback and leaves with exit code 5."""

@@ -93,3 +93,27 @@ def test_bench_traffic_figure_is_tied_to_the_kernel_sources(tmp_path, monkeypatc
     assert bench.pmc_traffic(12345)[0] is None
     # N * (12 + 12 + 8 + 8) + 12 M read, N * 32 written, over two passes
     assert bench.algorithmic_bytes_per_launch(1 << 20, 523884, 2) == ((1 << 20) * 72 + 523884 * 12) / 2
+
+
+def test_bench_last_gasp_line_on_a_fatal_signal():
+    """bench.py's C-level handler (LastGasp): a process that dies by abort() inside a C call still writes the line
+    that was prepared beforehand, exactly once, and leaves with exit code 6 (no GPU needed)."""
+    import textwrap
+    root = os.path.dirname(HERE)
+    code = textwrap.dedent(f'''
+        import ctypes, os, sys
+        sys.path.insert(0, {root!r})
+        import bench
+        g = bench.LastGasp(1)
+        g.arm(b'{{"value": 1, "extras_aborted": "overlap (fatal signal)"}}\\n')
+        g.arm(b'{{"value": 2, "extras_aborted": "config5 (fatal signal)"}}\\n')   # the later leg replaces the earlier line
+        ctypes.CDLL(None).abort()
+    ''')
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 6, (r.returncode, r.stderr[-500:])
+    assert r.stdout == '{"value": 2, "extras_aborted": "config5 (fatal signal)"}\n'
+    assert "fatal signal 6" in r.stderr
+    # disarmed: the default disposition is not restored, but nothing is written twice and the exit code still says "died"
+    code2 = code.replace("ctypes.CDLL(None).abort()", "g.disarm(); ctypes.CDLL(None).abort()")
+    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 6 and r.stdout == ""

@@ -1,12 +1,14 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): everything profiles/<tag>_* is made from, except the rocprofv3 passes
-# (tools/profile.sh, tools/profile_mid_n.sh).  usage: tools/collect_round.sh r02
+# (tools/profile.sh, tools/profile_routes.sh, tools/profile_mid_n.sh).  usage: tools/collect_round.sh r03 [full]
+# "full" adds the frame-loop / graph-policy probes of round 2 (frozen since: the GUI they serve is out of scope).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
+FULL=${2:-}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 cd $R
-python -m pytest tests -m gpu -q > $O/${TAG}_pytest_gpu.txt 2>&1; echo "pytest rc=$?"
+python -m pytest tests -m gpu -q --timeout 900 --timeout-method=thread > $O/${TAG}_pytest_gpu.txt 2>&1; echo "pytest rc=$?"
 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"
 NB_HIP_FORCE_SHARDED=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
     bench.py --gpus 1 --steps 10 --warmup 2 > $O/${TAG}_rehearsal_1rank.json 2> $O/${TAG}_rehearsal_1rank.err; echo "rehearsal rc=$?"
@@ -20,6 +22,12 @@ NB_HIP_FORCE_SHARDED=1 python -m torch.distributed.run --nnodes=1 --nproc-per-no
   echo "== oracle/_ref/nbody-bench-ref: the reference's own src/bench.c + src/lib/world.c + sim_cpu.c + galaxy.c, linked against libnbody_hip.so =="
   OMP_NUM_THREADS=16 ./oracle/_ref/nbody-bench-ref
 } > $O/${TAG}_nbody_bench_tables.txt 2>&1; echo "tables rc=$?"
+python tools/fused_probe.py time 200 250 300 512 > $O/${TAG}_fused_chain.txt 2>&1; echo "fused rc=$?"
+for P in 2 3; do
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node $P --master-addr 127.0.0.1 --master-port 2954$P bench.py --gpus $P \
+      --transport host --steps 10 --warmup 2 > $O/${TAG}_rehearsal_${P}ranks_host.json 2> $O/${TAG}_rehearsal_${P}ranks_host.err; echo "host-transport P=$P rc=$?"
+done
+[ "$FULL" = "full" ] || exit 0
 {
   echo "== tools/frame_probe.py: the reference GUI's frame loop through include/nbody.h (300 frames each), defaults =="
   python tools/frame_probe.py 6000 1000 100000
@@ -36,10 +44,6 @@ NB_HIP_FORCE_SHARDED=1 python -m torch.distributed.run --nnodes=1 --nproc-per-no
 python tools/odd_chain_probe.py > $O/${TAG}_odd_chain_probe.txt 2>&1; echo "odd rc=$?"
 python tools/first_call_probe.py > $O/${TAG}_first_call_probe.txt 2>&1; echo "first-call rc=$?"
 python tools/graph_chunk_probe.py > $O/${TAG}_graph_chunk_probe.txt 2>&1; echo "chunk rc=$?"
-for P in 2 3; do
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node $P --master-addr 127.0.0.1 --master-port 2954$P bench.py --gpus $P \
-      --transport host --steps 10 --warmup 2 > $O/${TAG}_rehearsal_${P}ranks_host.json 2> $O/${TAG}_rehearsal_${P}ranks_host.err; echo "host-transport P=$P rc=$?"
-done
 {
   echo "== clock ramp-up after host-side world setup: nbody-bench --gpu --n 20000 --n 50000 with longer warm-up calls (reference: 10 steps, bench.c:21) =="
   for w in 10 400 1600; do ./nbody_amd/lib/nbody-bench --gpu --n 20000 --n 50000 --warmup $w | tail -2 | cut -f2,3,6 | tr "\n" " "; echo " <- warm-up steps: $w"; done

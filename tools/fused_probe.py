@@ -28,7 +28,23 @@ def run(part, m, steps, **knobs):
 
 
 mode = sys.argv[1]
-if mode == "check":
+if mode == "msweep":
+    # fixed cost per step of the one-workgroup chain: N receivers, the first M of them massive
+    n = int(sys.argv[2])
+    rng = np.random.default_rng(1)
+    for m in [int(x) for x in sys.argv[3:]]:
+        a = np.zeros((n, 8), dtype=np.float32)
+        a[:, 0:2] = rng.standard_normal((n, 2)) * 1e4
+        a[:, 7] = 2.0
+        a[:m, 6] = 1e3
+        sim = nb.SimPipeline(n, m); sim.configure(fused_chain=1); sim.set_data(a)
+        sim.update(100, 0.01)
+        best = 1e9
+        for _ in range(5):
+            t0 = time.perf_counter(); sim.update(2000, 0.01); best = min(best, (time.perf_counter() - t0) / 2000)
+        sim.close()
+        print(f"N={n} M={m:4d}: {best*1e6:6.2f} us/step", flush=True)
+elif mode == "check":
     n, steps = int(sys.argv[2]), int(sys.argv[3])
     part, m = universe(n)
     print(f"N={n} M={m}: plain matched shape", flush=True)
