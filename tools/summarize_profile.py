@@ -13,8 +13,21 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out_dir = os.path.join(ROOT, "profiles")
 os.makedirs(out_dir, exist_ok=True)
 
+
+
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/, so a directory can hold several runs: per directory, the file
+    written last is the one this summary is about."""
+    best = {}
+    for f in glob.glob(pattern):
+        d = os.path.dirname(f)
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
+
+
 lines = []
-stats = glob.glob(os.path.join(PROF, "stats", "*", "*_kernel_stats.csv"))
+stats = newest(os.path.join(PROF, "stats", "*", "*_kernel_stats.csv"))
 step_avg_ns = None
 if stats:
     lines.append("== rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-extra-configs --steps 10 --warmup 2 ==")
@@ -24,7 +37,7 @@ if stats:
             step_avg_ns = float(r["AverageNs"])
     with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as f:
         f.write(open(stats[0]).read())
-    tr = glob.glob(os.path.join(PROF, "stats", "*", "*_kernel_trace.csv"))
+    tr = newest(os.path.join(PROF, "stats", "*", "*_kernel_trace.csv"))
     if tr:
         rows = [r for r in csv.DictReader(open(tr[0])) if "step_kernel" in r["Kernel_Name"]]
         if rows:
@@ -42,9 +55,19 @@ if stats:
                          f"scratch={r['Scratch_Size']}: mean {step_avg_ns:.0f} ns, min {min(durs)} ns, max {max(durs)} ns "
                          f"(the per-name rows above also hold the smaller launches of extra_configs C2 / C3)")
 
+# the profiled command's own JSON line: its HIP-event figure for the same launches must agree with the trace's mean
+_log = os.path.join(PROF, "stats.log")
+if os.path.exists(_log):
+    for _line in open(_log, errors="replace"):
+        if _line.startswith("{") and '"roofline"' in _line:
+            _rec = json.loads(_line)
+            lines.append(f"the profiled run's own bench line: roofline.kernel_ms_per_launch = {_rec['roofline']['kernel_ms_per_launch']:.3f} ms "
+                         f"(HIP events on the launch stream, incl. one ~10 us finish kernel per launch), ms_per_step = {_rec['ms_per_step']:.3f}, "
+                         f"frac = {_rec['roofline']['frac']:.4f}")
+
 # bench.py also times the LDS-tile route (roofline.alt_lds): the counters below are those of the HEADLINE variant only,
 # i.e. of the step_kernel instantiation with the most launches
-files = glob.glob(os.path.join(PROF, "pmc_*", "*", "*_counter_collection.csv"))
+files = newest(os.path.join(PROF, "pmc_*", "*", "*_counter_collection.csv"))
 names = collections.Counter(r["Kernel_Name"] for f in files for r in csv.DictReader(open(f)) if "step_kernel" in r["Kernel_Name"])
 headline = names.most_common(1)[0][0] if names else None
 agg = collections.defaultdict(list)

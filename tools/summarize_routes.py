@@ -12,9 +12,19 @@ PROF = os.path.join(ROOT, "gpurun_out", "prof_routes")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
+def newest(pattern):
+    """per directory, the file written last (gpurun merges every call's files into gpurun_out/)"""
+    best = {}
+    for f in glob.glob(pattern):
+        d = os.path.dirname(f)
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
+
+
 def collect(v):
     mean, kernel = {}, None
-    files = glob.glob(os.path.join(PROF, f"v{v}_pmc_*", "*", "*_counter_collection.csv"))
+    files = newest(os.path.join(PROF, f"v{v}_pmc_*", "*", "*_counter_collection.csv"))
     agg = collections.defaultdict(list)
     for f in files:
         for r in csv.DictReader(open(f)):
@@ -25,13 +35,13 @@ def collect(v):
             agg["_dur_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for k, vals in agg.items():
         mean[k] = sum(vals) / len(vals)
-    stats = glob.glob(os.path.join(PROF, f"v{v}_stats", "*", "*_kernel_stats.csv"))
+    stats = newest(os.path.join(PROF, f"v{v}_stats", "*", "*_kernel_stats.csv"))
     if stats:
         for r in csv.DictReader(open(stats[0])):
             if "step_kernel" in r["Name"]:
                 mean["_avg_ns_stats_pass"] = float(r["AverageNs"])
                 break
-    tr = glob.glob(os.path.join(PROF, f"v{v}_stats", "*", "*_kernel_trace.csv"))
+    tr = newest(os.path.join(PROF, f"v{v}_stats", "*", "*_kernel_trace.csv"))
     if tr:
         for r in csv.DictReader(open(tr[0])):
             if "step_kernel" in r["Kernel_Name"]:
