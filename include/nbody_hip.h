@@ -168,6 +168,12 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
  *               with plain launches for the remainder; on larger worlds a chain length runs as plain launches the first
  *               time it is asked for and as a cached hipGraph from the second time on (a replay saves nothing there).
  *               The step size is never baked into a chain: kernels read it from device memory.
+ *   "lanes"     lane groups per wave: 2 or 4 = the 64 lanes of a wave are that many groups over the SAME 64 / lanes receivers,
+ *               each group walking its own slice of the sources (w x lanes slices per receiver inside one workgroup: the
+ *               parallelism of a source split without its second kernel; sources staged once in LDS, k = 1, split = 1,
+ *               at most 8192 sources, unsharded whole steps only); 1 = never; 0 (default) = auto: latency-bound launches
+ *               (N x M <= 9e6, about N <= 4 000) whose other shape knobs are on auto -- 15-28 % faster there than the best
+ *               split shape (profiles/r03_lane_split_scan.txt)
  *   "fused_chain"  worlds that fit ONE 1024-thread workgroup (N <= 512) can run a whole n-step call inside one launch:
  *               positions in LDS, two workgroup barriers per step, no kernel boundary (1.6-1.8 us each, more than such a
  *               step's arithmetic).  2 (default) = auto: calls of 2+ steps while N <= 256 and N x M <= 3.6e4 (beyond that one
@@ -197,6 +203,9 @@ int nb_hip_configure(SimPipeline *sim, const char *key, int value);
 /* Steps of the last PerformSimUpdate / nb_hip_step_async that ran inside one-workgroup chain launches ("fused_chain"). */
 uint32_t nb_hip_last_fused_steps(const SimPipeline *sim);
 
+/* Lane groups per wave of the last step launch ("lanes" knob): 1, 2 or 4. */
+int nb_hip_launch_lanes(const SimPipeline *sim);
+
 /* What the last step launch actually used (after "auto"): fills k, w, variant, split, workgroups. */
 void nb_hip_launch_shape(const SimPipeline *sim, int *k, int *w, int *variant, int *split, uint32_t *workgroups);
 
@@ -207,6 +216,13 @@ void nb_hip_launch_shape(const SimPipeline *sim, int *k, int *w, int *variant, i
  * minimises rounds * work-per-workgroup, rounds = ceil(workgroups / resident slots).
  */
 void nb_hip_plan_launch(uint32_t n_recv, uint32_t n_src, int compute_units, int *k, int *w, int *split, uint32_t *workgroups);
+
+/*
+ * Whether an unsharded step of that size runs as a lane-split launch when every shape knob is on auto ("lanes" knob):
+ * returns the lane groups per wave (1 = no: the classic shape nb_hip_plan_launch describes is used) and, through w, the
+ * waves per workgroup.  Lane-split steps are ONE kernel (no finish kernel).
+ */
+int nb_hip_plan_launch_lanes(uint32_t n_recv, uint32_t n_src, int *w);
 
 /* The source-slice granule ("unit" knob: 64, 32, 16 or 8 sources) the same arithmetic picks for such a launch. */
 int nb_hip_plan_launch_unit(uint32_t n_recv, uint32_t n_src, int compute_units);

@@ -67,6 +67,7 @@ HIP_API = {
     "nb_hip_runtime_version": (C.c_int, []),
     "nb_hip_launch_unit": (C.c_int, [C.c_void_p]),
     "nb_hip_last_fused_steps": (C.c_uint32, [C.c_void_p]),
+    "nb_hip_launch_lanes": (C.c_int, [C.c_void_p]),
     "nb_hip_note_host_array": (None, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "nb_hip_configure": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "nb_hip_launch_shape": (None, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
@@ -74,6 +75,7 @@ HIP_API = {
     "nb_hip_plan_launch": (None, [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "nb_hip_plan_launch_unit": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int]),
+    "nb_hip_plan_launch_lanes": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_int)]),
     "nb_hip_comm_unique_id": (None, [C.c_void_p]),
     "CreateSimPipelineSharded": (C.c_void_p, [WorldData, C.c_int, C.c_int, C.c_void_p]),
     "CreateSimPipelineShardedWith": (C.c_void_p, [WorldData, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]),
@@ -163,10 +165,13 @@ def shard_plan(total_len, mass_len, rank, nranks):
 
 
 def plan_launch(n_recv, n_src, compute_units=256):
-    k, w, sp, g = C.c_int(), C.c_int(), C.c_int(), C.c_uint32()
+    """The classic (k, w, split, unit) plan, plus "lanes" / "lanes_w": whether an all-auto unsharded step of that size
+    runs as a lane-split launch instead (lanes > 1) and with how many waves per workgroup."""
+    k, w, sp, g, lw = C.c_int(), C.c_int(), C.c_int(), C.c_uint32(), C.c_int()
     hip_lib().nb_hip_plan_launch(n_recv, n_src, compute_units, C.byref(k), C.byref(w), C.byref(sp), C.byref(g))
+    lanes = int(hip_lib().nb_hip_plan_launch_lanes(n_recv, n_src, C.byref(lw)))
     return {"k": k.value, "w": w.value, "split": sp.value, "workgroups": g.value,
-            "unit": int(hip_lib().nb_hip_plan_launch_unit(n_recv, n_src, compute_units))}
+            "unit": int(hip_lib().nb_hip_plan_launch_unit(n_recv, n_src, compute_units)), "lanes": lanes, "lanes_w": lw.value}
 
 
 def comm_unique_id():
@@ -285,7 +290,8 @@ class SimPipeline:
         k, w, v, sp, g = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_uint32()
         hip_lib().nb_hip_launch_shape(self._h, C.byref(k), C.byref(w), C.byref(v), C.byref(sp), C.byref(g))
         return {"k": k.value, "w": w.value, "variant": "smem" if v.value else "lds", "split": sp.value,
-                "workgroups": g.value, "unit": int(hip_lib().nb_hip_launch_unit(self._h))}
+                "workgroups": g.value, "unit": int(hip_lib().nb_hip_launch_unit(self._h)),
+                "lanes": int(hip_lib().nb_hip_launch_lanes(self._h))}
 
 
 class LocalShardGroup:

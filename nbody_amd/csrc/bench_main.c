@@ -186,7 +186,9 @@ int main(int argc, char **argv) {
             /* passes: one launch per <= 3 MiB of (x, y, G*m) sources (step_chain.hip passes_for) */
             const uint32_t passes = m ? (uint32_t)(((uint64_t)m * 12 + (3u << 20) - 1) / (3u << 20)) : 1;
             nb_hip_plan_launch(n, (m + passes - 1) / passes, 256, &k, &wv, &split, &groups);
-            const double kernels = (double)passes * (split > 1 ? 2.0 : 1.0);
+            /* lane-split steps (small worlds, every knob on auto) are one kernel whatever the classic plan's split says */
+            const int lane_split = passes == 1 && nb_hip_plan_launch_lanes(n, m, NULL) > 1;
+            const double kernels = (double)passes * (split > 1 && !lane_split ? 2.0 : 1.0);
             const double floor_us = pairs / floor_rate * 1e6 + kernels * LAUNCH_FLOOR_US;
             printf("\t%11.3e\t%9.1f\t%8.2f\t%8.2f\t%9.1f", pairs / gpu_s, pairs / gpu_s * 14.0 / 157.3e12 * 100.0, gpu_s * 1e6,
                    floor_us, floor_us / (gpu_s * 1e6) * 100.0);

@@ -85,9 +85,19 @@ struct LaunchShape {
     int variant;  // VARIANT_*
     int split;    // workgroups per receiver tile (source parts): 1 .. MAX_SPLIT
     int unit;     // sources per slice granule: 64 (default), 32, 16, 8
+    // lane groups per wave (0 / 1: a wave's 64 lanes are 64 * k receivers).  2 or 4: the lanes of a wave split into that
+    // many groups over the SAME 64 / lanes receivers, each group walking its own slice of the sources (lane_split_kernel):
+    // w * lanes source slices per receiver inside ONE workgroup -- the parallelism a source split buys, without its
+    // second kernel.  Latency-bound launches only (k = 1, split = 1, sources staged once in LDS).
+    int lanes;
 };
 
+constexpr uint32_t LANE_SPLIT_MAX_SRC = 8192;   // sources a lane-split workgroup stages in LDS (12 B each)
+
 constexpr int MAX_SPLIT = 16;
+
+// The auto rule for lane-split shapes: lanes (1 = use the classic kernel) and waves per workgroup.
+int lane_split_rule(uint32_t n_recv, uint32_t n_src, int *w);
 
 // Resolve "auto" (0) entries of `want` for a launch over n_recv receivers and n_src sources.
 LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int compute_units);
@@ -96,6 +106,7 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
 const void *step_kernel_fn(LaunchShape s);
 dim3 step_grid(LaunchShape s, uint32_t n_recv);
 dim3 step_block(LaunchShape s);
+size_t step_lds_bytes(LaunchShape s, uint32_t n_src);   // dynamic LDS of the launch (0 except for lane-split shapes)
 // second kernel of a split step (split > 1): adds the parts and finishes like the step kernel's epilogue
 const void *finish_kernel_fn();
 dim3 finish_grid(uint32_t n_recv);

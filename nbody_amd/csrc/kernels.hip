@@ -475,6 +475,125 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
     }
 }
 
+// ---- lane-split step: several source slices per receiver inside one wave -------------------------------------------
+//
+// Between the one-workgroup chain (N <= 256) and launches that fill the chip (N >~ 20 000) a step is bound by latency:
+// the kernel boundary plus one wave's dependency chain over its slice of the sources.  The source split shortens the
+// chain by giving a receiver tile to several workgroups -- and pays a second dependent kernel (the finish kernel,
+// 1.7 us of boundary + ~1 us of its own) to add their sums.  Here the extra slices live INSIDE the wave instead: the 64
+// lanes are `H` groups over the same 64 / H receivers, every group walks its own slice, and the W x H partial sums meet
+// in LDS like the W of the ordinary kernel.  Lanes of different groups need different sources at the same time, so the
+// source cannot be a wave-uniform scalar operand: the workgroup stages the sources once in LDS (coalesced loads, one
+// barrier) and every lane reads its own -- per-lane data is what LDS is for (cf. "Why the LDS-tile route trails").
+// K = 1, split = 1, slices in 8-source granules, Kahan block closes every 256 sources of a lane's slice.
+template <int W, int H>
+__global__ __launch_bounds__(WAVE *W) void lane_split_kernel(const StepParams p) {
+    constexpr uint32_t R = WAVE / H;   // receivers per workgroup
+    constexpr uint32_t V = W * H;      // source slices per receiver
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const uint32_t n0 = p.src_end[0] - p.src_begin[0];
+    const uint32_t n0_pad = (n0 + 7u) & ~7u;
+    float2 *sxy = reinterpret_cast<float2 *>(lds_raw);
+    float *sgm = reinterpret_cast<float *>(sxy + n0_pad);
+    float2 *partial = reinterpret_cast<float2 *>(sgm + n0_pad);   // [V][R]
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (WAVE - 1);
+    const uint32_t wid = tid >> 6;
+    const uint32_t r = lane % R, h = lane / R;
+    const float dt = *p.dt;
+
+    // stage every source once: coalesced float2 / float loads, 12 bytes per source
+    for (uint32_t j = tid; j < n0; j += WAVE * W) {
+        sxy[j] = p.src_pos[p.src_begin[0] + j];
+        sgm[j] = p.src_gm[p.src_begin[0] + j];
+    }
+    Receivers<1> Rv;
+    {
+        uint32_t i = blockIdx.x * R + r;
+        i = i < p.n_recv ? i : p.n_recv - 1;  // tail lanes redo the last receiver; the epilogue masks them
+        i = receiver_slot(p, i);
+        const float2 q = p.pos_in[i];
+        Rv.p[0] = f2v{q.x, q.y};
+        Rv.r[0] = p.radius[i];
+    }
+    Rv.clear();
+
+    // slice v = wid * H + h of V, in whole 8-source granules; empty slices have v_hi == v_lo (clamped: no wrap-around)
+    const uint32_t v = wid * H + h;
+    const uint32_t nunits = (n0 + 7u) / 8u;
+    const uint32_t per = (nunits + V - 1) / V;
+    const uint32_t u_lo = min(v * per, nunits);
+    const uint32_t u_hi = min(u_lo + per, nunits);
+    const uint32_t v_lo = u_lo * 8u;
+    const uint32_t v_hi = max(min(u_hi * 8u, n0), v_lo);
+    __syncthreads();
+
+    // Four sources per group: two 16-byte reads of positions, one of G*m (lanes of one lane group read the same address,
+    // the groups different ones).  The next group's reads are issued before this group's arithmetic: a lane's slice is a
+    // serial chain, and an LDS round trip (~64+ cycles) per four interactions would otherwise sit on it.
+    uint32_t j = v_lo;
+    const uint32_t groups = (v_hi - v_lo) / 4u;
+    v4f P01 = {0.f, 0.f, 0.f, 0.f}, P23 = {0.f, 0.f, 0.f, 0.f}, G4 = {0.f, 0.f, 0.f, 0.f};
+    if (groups > 0) {
+        P01 = *reinterpret_cast<const v4f *>(&sxy[j]);
+        P23 = *reinterpret_cast<const v4f *>(&sxy[j + 2]);
+        G4 = *reinterpret_cast<const v4f *>(&sgm[j]);
+    }
+    for (uint32_t g = 0; g < groups; g++) {
+        const v4f A01 = P01, A23 = P23, AG = G4;
+        const uint32_t jn = g + 1 < groups ? j + 4 : j;   // the last group re-reads itself instead of branching
+        P01 = *reinterpret_cast<const v4f *>(&sxy[jn]);
+        P23 = *reinterpret_cast<const v4f *>(&sxy[jn + 2]);
+        G4 = *reinterpret_cast<const v4f *>(&sgm[jn]);
+        interact<1, false>(Rv, f2v{A01[0], A01[1]}, AG[0]);
+        interact<1, false>(Rv, f2v{A01[2], A01[3]}, AG[1]);
+        interact<1, false>(Rv, f2v{A23[0], A23[1]}, AG[2]);
+        interact<1, false>(Rv, f2v{A23[2], A23[3]}, AG[3]);
+        j += 4;
+        if (((j - v_lo) & (CHUNK * CLOSE_EVERY - 1)) == 0) Rv.close_chunk();
+    }
+    for (; j < v_hi; j++) {
+        const float2 a0 = sxy[j];
+        interact<1, false>(Rv, f2v{a0.x, a0.y}, sgm[j]);
+    }
+    if ((v_hi - v_lo) & (CHUNK * CLOSE_EVERY - 1)) Rv.close_chunk();
+
+    // W x H partial sums per receiver meet in LDS.  Two levels, fixed order: thread (c, r) of the first wave adds the
+    // slices [c * V / S, (c + 1) * V / S) of receiver r, then thread r adds those S sums -- 64 dependent adds by 16
+    // threads would be the longest serial chain of a short launch.
+    partial[v * R + r] = make_float2(Rv.s[0].x, Rv.s[0].y);
+    __syncthreads();
+    constexpr uint32_t S = WAVE / R;        // = H second-level terms per receiver, computed by the first wave's 64 lanes
+    constexpr uint32_t PER = V / S;         // = W slices per first-level sum
+    if (wid == 0) {
+        const uint32_t c = lane / R, rr = lane % R;
+        float sx = 0.0f, sy = 0.0f;
+#pragma unroll
+        for (uint32_t s2 = 0; s2 < PER; s2++) {
+            const float2 t = partial[(c * PER + s2) * R + rr];
+            sx = __fadd_rn(sx, t.x);
+            sy = __fadd_rn(sy, t.y);
+        }
+        // same wave: LDS executes one wave's accesses in order; the fences only stop the compiler from reordering
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        partial[V * R + lane] = make_float2(sx, sy);   // second-level buffer behind the first: [S][R]
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < R) {
+            float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+            for (uint32_t c2 = 0; c2 < S; c2++) {
+                const float2 t = partial[V * R + c2 * R + lane];
+                ax = __fadd_rn(ax, t.x);
+                ay = __fadd_rn(ay, t.y);
+            }
+            finish_receiver(p, blockIdx.x * R + lane, ax, ay, dt);
+        }
+    }
+}
+
 // ---- the one-workgroup chain -------------------------------------------------------------------------------------
 //
 // Worlds of a few hundred particles are bound by the kernel boundary, not by arithmetic: at N = 250 a step is 30 000
@@ -674,6 +793,14 @@ const void *pick(int k, int w) {
     return nullptr;
 }
 
+const void *pick_lane_split(int w, int h) {
+#define NB_CASE(WW, HH) \
+    if (w == WW && h == HH) return reinterpret_cast<const void *>(&lane_split_kernel<WW, HH>);
+    NB_CASE(4, 2) NB_CASE(8, 2) NB_CASE(16, 2) NB_CASE(4, 4) NB_CASE(8, 4) NB_CASE(16, 4) NB_CASE(8, 8) NB_CASE(16, 8)
+#undef NB_CASE
+    return nullptr;
+}
+
 }  // namespace
 
 // NB_HASH_OFF -- host-side launch-shape arithmetic: not part of the kernel-source hash bench.py ties PMC figures to
@@ -718,6 +845,29 @@ static double small_launch_cost_us(uint32_t n_recv, uint32_t n_src, int k, int w
     return t + BASE;  // what every step pays whatever its shape (dispatch, kernel boundary): keeps ties ties
 }
 
+// Lane-split shapes ("lanes" = 0, auto), from a scan of lanes x w over N = 300 ... 10 000 (tools/lane_probe.py,
+// profiles/r03_lane_split_scan.txt; us per step, best lane-split shape vs the best classic shape the model above picks):
+//   N = 500: 3.11 vs 3.86   800: 3.25 vs 4.25   1 200: 3.70 vs 4.98   2 000: 3.93 vs 5.41   4 000: 5.88 vs 6.93
+//   5 000: 8.62 vs 8.42     8 000: 13.3 vs 12.7   10 000: 20.6 vs 15.8
+// i.e. 15-28 % faster while a step is latency (N x M <~ 9e6), slower once it is throughput: every workgroup stages ALL
+// the sources in LDS and the per-lane LDS reads cost issue slots a wave-uniform scalar operand does not.  Which (lanes, w)
+// wins moves with the size; neighbours are within 2-3 % of each other.
+int lane_split_rule(uint32_t n_recv, uint32_t n_src, int *w) {
+    const double pairs = (double)n_recv * (double)n_src;
+    *w = 16;
+    if (n_src == 0 || n_recv == 0 || n_src > LANE_SPLIT_MAX_SRC || pairs > 9.0e6) return 1;
+    if (pairs <= 1.5e5) {
+        *w = 8;
+        return 4;
+    }
+    if (pairs <= 6.0e5) {
+        *w = 8;
+        return 8;
+    }
+    if (pairs <= 2.5e6) return 8;
+    return 4;
+}
+
 LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int compute_units) {
     // Workgroups of one launch all take the same time, so a launch costs
     //     (rounds + tail) * (work per workgroup),   rounds = ceil(workgroups / resident capacity),
@@ -727,10 +877,30 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
     // smaller split.  More, shorter workgroups also shrink the launch's ramp-up/ragged-end share.  K = 4 is left out: 71 VGPRs, lower
     // occupancy, never faster (profiles/r01_sweep4_shapes_by_n.txt).
     if (compute_units <= 0) compute_units = 256;
+    if (want.lanes == 0 && want.k == 0 && want.w == 0 && want.split == 0 && want.unit == 0 && want.variant == VARIANT_SMEM) {
+        // everything on auto (an explicit LDS-tile route or shape knob asks for the classic kernel)
+        int w = 16;
+        const int lanes = lane_split_rule(n_recv, n_src, &w);
+        if (lanes > 1) {
+            want.lanes = lanes;
+            want.w = w;
+        }
+    }
+    if (want.lanes > 1) {
+        // one receiver per lane, no source split, 8-source granules, LDS-staged sources
+        LaunchShape sh = want;
+        sh.k = 1;
+        sh.w = (want.w == 4 || want.w == 8 || want.w == 16) ? want.w : 16;
+        sh.split = 1;
+        sh.unit = 8;
+        sh.variant = VARIANT_LDS;
+        return sh;
+    }
     if (want.variant == VARIANT_LDS) want.unit = CHUNK;  // the LDS route stages whole 64-source tiles, whatever was asked
     const uint32_t chunks = (n_src + CHUNK - 1) / CHUNK;
     const bool small = ((uint64_t)n_recv + 2 * WAVE - 1) / (2 * WAVE) < (uint64_t)compute_units * 2;
     LaunchShape best = want;
+    best.lanes = 1;
     double best_cost = -1.0;
     for (int k = 2; k >= 1; k--) {
         if (want.k != 0 && want.k != k) continue;
@@ -793,11 +963,19 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
 
 // NB_HASH_ON
 const void *step_kernel_fn(LaunchShape s) {
+    if (s.lanes > 1) return pick_lane_split(s.w, s.lanes);
     return s.variant == VARIANT_SMEM ? pick<VARIANT_SMEM>(s.k, s.w) : pick<VARIANT_LDS>(s.k, s.w);
 }
 
 dim3 step_grid(LaunchShape s, uint32_t n_recv) {
+    if (s.lanes > 1) return dim3((n_recv + WAVE / s.lanes - 1) / (WAVE / s.lanes), 1);
     return dim3((n_recv + WAVE * s.k - 1) / (WAVE * s.k), s.split > 1 ? s.split : 1);
+}
+
+size_t step_lds_bytes(LaunchShape s, uint32_t n_src) {
+    if (s.lanes <= 1) return 0;
+    const size_t pad = ((size_t)n_src + 7u) & ~(size_t)7u;
+    return pad * 12 + ((size_t)s.w + 1) * WAVE * sizeof(float2);   // sources (x, y, G*m) + [w * lanes][64 / lanes] partial sums + 64 second-level sums
 }
 const void *finish_kernel_fn() { return reinterpret_cast<const void *>(&finish_kernel); }
 dim3 finish_grid(uint32_t n_recv) { return dim3((n_recv + 255u) / 256u); }

@@ -176,6 +176,8 @@ SimPipeline *CreateSimPipeline(WorldData data) {
     if (zc) s->zero_copy_upload = atoi(zc) ? 1 : 0;
     const char *tm = getenv("NB_HIP_TIMING");
     if (tm) s->timing = atoi(tm) ? 1 : 0;
+    const char *ln = getenv("NB_HIP_LANES");
+    if (ln) s->want_lanes = atoi(ln);
     const char *fc = getenv("NB_HIP_FUSED_CHAIN");
     if (fc) s->fused_chain = atoi(fc) < 0 || atoi(fc) > 2 ? 2 : atoi(fc);
     const char *gr = getenv("NB_HIP_GRAPH");
@@ -219,7 +221,7 @@ SimPipeline *CreateSimPipelineShardedWith(WorldData data, int rank, int nranks, 
 }
 
 void nb_hip_plan_launch(uint32_t n_recv, uint32_t n_src, int compute_units, int *k, int *w, int *split, uint32_t *workgroups) {
-    const nb::LaunchShape sh = nb::choose_shape({0, 0, nb::VARIANT_SMEM, 0, 0}, n_recv, n_src, compute_units);
+    const nb::LaunchShape sh = nb::choose_shape({0, 0, nb::VARIANT_SMEM, 0, 0, 1}, n_recv, n_src, compute_units);
     if (k) *k = sh.k;
     if (w) *w = sh.w;
     if (split) *split = sh.split;
@@ -229,8 +231,15 @@ void nb_hip_plan_launch(uint32_t n_recv, uint32_t n_src, int compute_units, int 
     }
 }
 
+int nb_hip_plan_launch_lanes(uint32_t n_recv, uint32_t n_src, int *w) {
+    int ww = 16;
+    const int lanes = n_src <= nb::LANE_SPLIT_MAX_SRC ? nb::lane_split_rule(n_recv, n_src, &ww) : 1;
+    if (w) *w = ww;
+    return lanes;
+}
+
 int nb_hip_plan_launch_unit(uint32_t n_recv, uint32_t n_src, int compute_units) {
-    return nb::choose_shape({0, 0, nb::VARIANT_SMEM, 0, 0}, n_recv, n_src, compute_units).unit;
+    return nb::choose_shape({0, 0, nb::VARIANT_SMEM, 0, 0, 1}, n_recv, n_src, compute_units).unit;
 }
 
 int nb_hip_local_group_create(WorldData data, int nranks, SimPipeline **out) {
@@ -469,6 +478,11 @@ uint32_t nb_hip_last_fused_steps(const SimPipeline *s) {
     return s->fused_steps;
 }
 
+int nb_hip_launch_lanes(const SimPipeline *s) {
+    NB_ASSERT(s != nullptr, "NULL pipeline");
+    return s->last_shape.lanes > 1 ? s->last_shape.lanes : 1;
+}
+
 int nb_hip_launch_unit(const SimPipeline *s) {
     NB_ASSERT(s != nullptr, "NULL pipeline");
     return s->last_shape.unit;
@@ -512,6 +526,10 @@ int nb_hip_configure(SimPipeline *s, const char *key, int value) {
         NB_ASSERT(value >= 0 && value <= 2, "graph must be 0 (never), 1 (always) or 2 (from the second use), got %d", value);
         old = s->use_graph;
         s->use_graph = value;
+    } else if (!strcmp(key, "lanes")) {
+        NB_ASSERT(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, "lanes must be 0 (auto), 1, 2, 4 or 8, got %d", value);
+        old = s->want_lanes;
+        s->want_lanes = value;
     } else if (!strcmp(key, "fused_chain")) {
         NB_ASSERT(value >= 0 && value <= 2, "fused_chain must be 0 (never), 1 (whenever the world fits one workgroup) or 2 (auto), got %d", value);
         old = s->fused_chain;

@@ -60,13 +60,27 @@ void destroy_graph(StepGraph &g) {
 }
 
 nb::LaunchShape resolve_shape(SimPipeline *s) {
-    nb::LaunchShape want = {s->want_k, s->want_w, s->want_variant, s->want_split, s->want_unit};
+    nb::LaunchShape want = {s->want_k, s->want_w, s->want_variant, s->want_split, s->want_unit, s->want_lanes};
     // the model sees one launch: with source passes that is 1/passes of the sources
     nb::StepParams probe;
     memset(&probe, 0, sizeof probe);
     probe.src_end[0] = s->n_src;
     const uint32_t passes = (s->sharded && s->overlap) ? 1 : passes_for(s, probe);
+    // lane-split shapes stage ALL sources of the launch in LDS and walk one source range: whole unsharded steps only
+    if (s->sharded || passes != 1 || s->n_src > nb::LANE_SPLIT_MAX_SRC || s->n_src == 0) want.lanes = want.lanes > 1 ? 1 : want.lanes;
     nb::LaunchShape sh = nb::choose_shape(want, s->n_real, (s->n_src + passes - 1) / passes, g_dev.compute_units);
+    if (s->sharded || passes != 1 || s->n_src > nb::LANE_SPLIT_MAX_SRC || s->n_src == 0) sh.lanes = 1;
+    if (sh.lanes > 1) {
+        // the kernels may need more than the 64 KB of dynamic LDS a launch gets by default: raise the limit once per kernel
+        static std::vector<const void *> raised;
+        const void *fn = nb::step_kernel_fn(sh);
+        bool done = false;
+        for (const void *f : raised) done = done || f == fn;
+        if (!done && fn) {
+            ASSERT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "raise the dynamic LDS limit");
+            raised.push_back(fn);
+        }
+    }
     NB_ASSERT(nb::step_kernel_fn(sh) != nullptr, "no step kernel for k=%d w=%d variant=%d", sh.k, sh.w, sh.variant);
     if (sh.split > 1) {
         const size_t need = (size_t)sh.split * s->n_real;
@@ -162,7 +176,8 @@ void launch_step(SimPipeline *s, nb::LaunchShape sh, const nb::StepParams &p, hi
     if (s->n_real == 0) return;  // a rank without receivers still takes part in the gathers
     for (nb::StepParams &copy : step_passes(s, p, sh)) {
         void *args[] = {&copy};
-        ASSERT_HIP(hipLaunchKernel(nb::step_kernel_fn(sh), nb::step_grid(sh, s->n_real), nb::step_block(sh), args, 0, st),
+        ASSERT_HIP(hipLaunchKernel(nb::step_kernel_fn(sh), nb::step_grid(sh, s->n_real), nb::step_block(sh), args,
+                                   nb::step_lds_bytes(sh, copy.src_end[0] - copy.src_begin[0]), st),
                    "step kernel launch (k=%d w=%d variant=%d split=%d, %u receivers)", sh.k, sh.w, sh.variant, sh.split,
                    s->n_real);
         if (copy.split > 1)
@@ -182,12 +197,12 @@ void upload_dt(SimPipeline *s, float dt) {
 
 // ---- single-device chains ------------------------------------------------------------------------------------
 
-void fill_node(hipKernelNodeParams &kp, void **args, const void *fn, dim3 grid, dim3 block) {
+void fill_node(hipKernelNodeParams &kp, void **args, const void *fn, dim3 grid, dim3 block, size_t lds_bytes = 0) {
     memset(&kp, 0, sizeof kp);
     kp.func = const_cast<void *>(fn);
     kp.gridDim = grid;
     kp.blockDim = block;
-    kp.sharedMemBytes = 0;
+    kp.sharedMemBytes = (unsigned int)lds_bytes;
     kp.kernelParams = args;
     kp.extra = nullptr;
 }
@@ -199,7 +214,7 @@ void fill_node(hipKernelNodeParams &kp, void **args, const void *fn, dim3 grid, 
 StepGraph *find_graph(SimPipeline *s, uint32_t n, uint32_t passes, nb::LaunchShape sh, int phase) {
     for (auto &c : s->graphs)
         if (c.n == n && c.passes == passes && c.phase == phase && c.shape.k == sh.k && c.shape.w == sh.w &&
-            c.shape.variant == sh.variant && c.shape.split == sh.split && c.shape.unit == sh.unit)
+            c.shape.variant == sh.variant && c.shape.split == sh.split && c.shape.unit == sh.unit && c.shape.lanes == sh.lanes)
             return &c;
     return nullptr;
 }
@@ -232,7 +247,8 @@ StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchS
             for (uint32_t j = 0; j < per_pass; j++) {
                 hipKernelNodeParams kp;
                 if (j == 0)
-                    fill_node(kp, args, nb::step_kernel_fn(sh), nb::step_grid(sh, s->n_real), nb::step_block(sh));
+                    fill_node(kp, args, nb::step_kernel_fn(sh), nb::step_grid(sh, s->n_real), nb::step_block(sh),
+                              nb::step_lds_bytes(sh, launches[q].src_end[0] - launches[q].src_begin[0]));
                 else
                     fill_node(kp, args, nb::finish_kernel_fn(), nb::finish_grid(s->n_real), nb::finish_block());
                 hipGraphNode_t &node = g->nodes[(size_t)i * per_step + q * per_pass + j];
@@ -293,7 +309,7 @@ void enqueue_fused(SimPipeline *s, uint32_t n) {
         left -= p.steps;
     }
     s->fused_steps = n;
-    s->last_shape = {2, (int)(16u / p.tiles), nb::VARIANT_LDS, 1, 8};   // the per-step shape it is bit-equal to
+    s->last_shape = {2, (int)(16u / p.tiles), nb::VARIANT_LDS, 1, 8, 1};   // the per-step shape it is bit-equal to
     s->last_groups = 1;
 }
 

@@ -462,6 +462,95 @@ def test_fused_chain_ragged_worlds(n, frac):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# lane-split launches (knob "lanes"): several source slices per receiver inside one wave, sources staged in LDS
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("lanes,w", [(2, 4), (2, 16), (4, 8), (4, 16), (8, 8), (8, 16)])
+def test_lane_split_shapes_against_float64(golden, lanes, w):
+    """Every lane-split instantiation against float64 and the integrator's exact roundings, at the fixtures and at
+    source counts around every granule / group / slice boundary (a slice is a whole number of 8-source granules, walked in
+    groups of four; trailing slices are empty), with receivers that do not fill the last workgroup."""
+    for n in (4096, 333):
+        part, m = ob.partition(golden(f"ic_{n}.bin"))
+        sim = nb.SimPipeline(n, m)
+        sim.configure(lanes=lanes, w=w)
+        sim.set_data(part)
+        sim.update(1, 0.01)
+        shape = sim.launch_shape()
+        got = sim.get_data()
+        sim.close()
+        assert (shape["lanes"], shape["w"], shape["k"], shape["split"]) == (lanes, w, 1, 1)
+        assert shape["workgroups"] == -(-n // (64 // lanes))
+        check_one_step(got, part, m, 0.01)
+    for m_want in (1, 3, 4, 5, 7, 8, 9, 31, 32, 33, 63, 64, 65, 100, 255, 256, 257, 511, 513, 1000, 1031, 2049):
+        n = m_want + 37
+        part, m = synth(n, 1.0, seed=50 + m_want)
+        part[m_want:, 6] = 0.0
+        part, m = ob.partition(part)
+        assert m == m_want
+        got = run(part, m, 1, 0.01, lanes=lanes, w=w)
+        check_one_step(got, part, m, 0.01)
+    # graph replay == plain launches, and a second step reads the first one's output
+    part, m = ob.partition(golden("ic_1024.bin"))
+    assert run(part, m, 5, 0.01, lanes=lanes, w=w, graph=1).tobytes() == run(part, m, 5, 0.01, lanes=lanes, w=w, graph=0).tobytes()
+
+
+def test_lane_split_auto_policy_and_multi_step_parity():
+    """All knobs on auto: latency-bound unsharded steps (N x M <= 9e6) run lane-split -- ONE kernel per step where the
+    classic model would split the sources and add a finish kernel; larger worlds, sharded pipelines, an explicit shape
+    knob or the LDS-tile route keep the classic kernel.  Ten steps against the reference's AVX stepper."""
+    for n, expect in ((300, True), (500, True), (2000, True), (4000, True), (10000, False), (65536, False)):
+        _, part, m = bench_universe(n)
+        plan = nb.plan_launch(n, m)
+        assert (plan["lanes"] > 1) == expect, (n, plan)
+        sim = nb.SimPipeline(n, m)
+        sim.set_data(part)
+        sim.update(10, 0.01)
+        shape = sim.launch_shape()
+        ms, launches = sim.last_step_ms()
+        got = sim.get_data()
+        sim.close()
+        assert (shape["lanes"] > 1) == expect, (n, shape)
+        if expect:
+            assert (shape["lanes"], shape["w"]) == (plan["lanes"], plan["lanes_w"]) and launches == 10 and shape["split"] == 1
+        if n <= 4000:
+            want = ob.step(part, m, 0.01, 10, kind="avx")
+            assert rel_l2_pos(got, want) <= 1e-6 and rel_displacement(got, want, part) <= DISPLACEMENT_TOL, n
+    _, part, m = bench_universe(2000)
+    for knobs in (dict(k=2), dict(w=8), dict(split=3), dict(unit=16), dict(variant=0), dict(lanes=1)):
+        sim = nb.SimPipeline(2000, m)
+        sim.configure(**knobs)
+        sim.set_data(part)
+        sim.update(1, 0.01)
+        assert sim.launch_shape()["lanes"] == 1, knobs
+        sim.close()
+    g = nb.LocalShardGroup(2000, m, 2)
+    g.set_data(part)
+    g.step(1, 0.01)
+    assert g.members[0].launch_shape()["lanes"] == 1
+    g.close()
+    # deterministic, and the same bits through the World surface
+    a = run(part, m, 3, 0.01)
+    assert a.tobytes() == run(part, m, 3, 0.01).tobytes()
+    w = nb.World(nb.make_galaxies(2000, 2, seed=11037))
+    w.update_gpu(0.01, 3)
+    assert w.particles().tobytes() == a.tobytes()
+    w.close()
+
+
+@pytest.mark.parametrize("n,frac", [(1, 1.0), (2, 0.5), (15, 1.0), (16, 0.5), (17, 1.0), (63, 0.5), (64, 1.0), (65, 0.3), (130, 1.0),
+                                    (257, 0.02), (300, 0.0), (1000, 0.01)])
+def test_lane_split_ragged_worlds(n, frac):
+    part, m = synth(n, frac, seed=3 * n + 1)
+    for lanes, w in ((4, 8), (8, 16), (2, 16)):
+        got = run(part, m, 1, 0.02, lanes=lanes, w=w, fused_chain=0)
+        check_one_step(got, part, m, 0.02)
+        two = run(part, m, 2, 0.02, lanes=lanes, w=w, fused_chain=0)
+        again = run(got, m, 1, 0.02, lanes=lanes, w=w, fused_chain=0)   # step 2 from step 1's output: the same bits
+        assert two.tobytes() == again.tobytes()
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # kernel properties: determinism, variants, linearity, edge shapes
 # ---------------------------------------------------------------------------------------------------------------
 
@@ -523,6 +612,7 @@ def test_fine_source_granules(unit):
 def test_auto_shape_uses_fine_granules_on_small_worlds(golden):
     part, m = ob.partition(golden("ic_333.bin"))
     sim = nb.SimPipeline(333, m)
+    sim.configure(lanes=1)          # the classic kernel's shape model (the all-auto default is a lane-split launch here)
     sim.set_data(part)
     sim.update(2, 0.01)
     shape = sim.launch_shape()
