@@ -67,9 +67,8 @@ nb::LaunchShape resolve_shape(SimPipeline *s) {
     probe.src_end[0] = s->n_src;
     const uint32_t passes = (s->sharded && s->overlap) ? 1 : passes_for(s, probe);
     // lane-split shapes stage ALL sources of the launch in LDS and walk one source range: whole unsharded steps only
-    if (s->sharded || passes != 1 || s->n_src > nb::LANE_SPLIT_MAX_SRC || s->n_src == 0) want.lanes = want.lanes > 1 ? 1 : want.lanes;
+    if (s->sharded || passes != 1 || s->n_src > nb::LANE_SPLIT_MAX_SRC || s->n_src == 0) want.lanes = 1;   // never, not "auto"
     nb::LaunchShape sh = nb::choose_shape(want, s->n_real, (s->n_src + passes - 1) / passes, g_dev.compute_units);
-    if (s->sharded || passes != 1 || s->n_src > nb::LANE_SPLIT_MAX_SRC || s->n_src == 0) sh.lanes = 1;
     if (sh.lanes > 1) {
         // the kernels may need more than the 64 KB of dynamic LDS a launch gets by default: raise the limit once per kernel
         static std::vector<const void *> raised;

@@ -688,8 +688,9 @@ def test_auto_shape_reports_its_choice(golden):
     sim.update(1, 0.01)
     shape = sim.launch_shape()
     sim.close()
-    assert shape["k"] in (1, 2) and shape["w"] in (4, 8, 16) and 1 <= shape["split"] <= 16
-    assert shape["workgroups"] == -(-4096 // (64 * shape["k"])) * shape["split"]
+    assert shape["k"] in (1, 2) and shape["w"] in (4, 8, 16) and 1 <= shape["split"] <= 16 and shape["lanes"] in (1, 2, 4, 8)
+    # classic: tiles of 64 * k receivers x source parts; lane-split: 64 / lanes receivers per workgroup, one part
+    assert shape["workgroups"] == -(-4096 * shape["lanes"] // (64 * shape["k"])) * shape["split"]
 
 
 def test_acc_is_linear_in_mass_by_powers_of_two(golden):
