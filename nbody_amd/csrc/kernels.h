@@ -92,7 +92,7 @@ struct LaunchShape {
     int lanes;
 };
 
-constexpr uint32_t LANE_SPLIT_MAX_SRC = 8192;   // sources a lane-split workgroup stages in LDS (12 B each)
+constexpr uint32_t LANE_SPLIT_MAX_SRC = 1u << 18;   // sources a lane-split launch walks (one launch = one source pass)
 
 constexpr int MAX_SPLIT = 16;
 

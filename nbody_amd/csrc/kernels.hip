@@ -483,31 +483,43 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
 // 1.7 us of boundary + ~1 us of its own) to add their sums.  Here the extra slices live INSIDE the wave instead: the 64
 // lanes are `H` groups over the same 64 / H receivers, every group walks its own slice, and the W x H partial sums meet
 // in LDS like the W of the ordinary kernel.  Lanes of different groups need different sources at the same time, so the
-// source cannot be a wave-uniform scalar operand: the workgroup stages the sources once in LDS (coalesced loads, one
-// barrier) and every lane reads its own -- per-lane data is what LDS is for (cf. "Why the LDS-tile route trails").
-// K = 1, split = 1, slices in 8-source granules, Kahan block closes every 256 sources of a lane's slice.
+// source cannot be a wave-uniform scalar operand: the workgroup stages the sources in LDS, tile by tile (2 x 64 x W
+// sources per tile, coalesced loads, fetched into registers one tile ahead), and every lane reads its own slice of the
+// tile -- per-lane data is what LDS is for (cf. "Why the LDS-tile route trails").  K = 1, split = 1, slices in 8-source
+// granules, Kahan block closes every 256 sources a lane has added.
 template <int W, int H>
 __global__ __launch_bounds__(WAVE *W) void lane_split_kernel(const StepParams p) {
-    constexpr uint32_t R = WAVE / H;   // receivers per workgroup
-    constexpr uint32_t V = W * H;      // source slices per receiver
+    constexpr uint32_t R = WAVE / H;        // receivers per workgroup
+    constexpr uint32_t V = W * H;           // source slices per receiver
+    constexpr uint32_t T = 2 * WAVE * W;    // sources per staged tile: two per thread (12 KB at W = 8, 24 KB at W = 16)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const uint32_t n0 = p.src_end[0] - p.src_begin[0];
-    const uint32_t n0_pad = (n0 + 7u) & ~7u;
     float2 *sxy = reinterpret_cast<float2 *>(lds_raw);
-    float *sgm = reinterpret_cast<float *>(sxy + n0_pad);
-    float2 *partial = reinterpret_cast<float2 *>(sgm + n0_pad);   // [V][R]
+    float *sgm = reinterpret_cast<float *>(sxy + T);
+    float2 *partial = reinterpret_cast<float2 *>(sgm + T);   // [V][R], then [S][R]
+    const uint32_t n0 = p.src_end[0] - p.src_begin[0];
+    const uint32_t ntiles = (n0 + T - 1) / T;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (WAVE - 1);
     const uint32_t wid = tid >> 6;
     const uint32_t r = lane % R, h = lane / R;
+    const uint32_t v = wid * H + h;         // this lane's slice of every tile
     const float dt = *p.dt;
 
-    // stage every source once: coalesced float2 / float loads, 12 bytes per source
-    for (uint32_t j = tid; j < n0; j += WAVE * W) {
-        sxy[j] = p.src_pos[p.src_begin[0] + j];
-        sgm[j] = p.src_gm[p.src_begin[0] + j];
-    }
+    // tile t of the sources, two per thread, fetched into registers one tile ahead (coalesced float2 / float loads);
+    // indices past the end are clamped -- the walk below never reads those LDS entries
+    float2 q0 = make_float2(0.f, 0.f), q1 = q0;
+    float m0 = 0.f, m1 = 0.f;
+    auto fetch = [&](uint32_t t) {
+        const uint32_t last = p.src_begin[0] + n0 - 1;
+        const uint32_t j0 = min(p.src_begin[0] + t * T + tid, last), j1 = min(j0 + WAVE * W, last);
+        q0 = p.src_pos[j0];
+        q1 = p.src_pos[j1];
+        m0 = p.src_gm[j0];
+        m1 = p.src_gm[j1];
+    };
+    if (ntiles > 0) fetch(0);
+
     Receivers<1> Rv;
     {
         uint32_t i = blockIdx.x * R + r;
@@ -518,62 +530,82 @@ __global__ __launch_bounds__(WAVE *W) void lane_split_kernel(const StepParams p)
         Rv.r[0] = p.radius[i];
     }
     Rv.clear();
+    uint32_t open_groups = 0;   // groups of four added since the last block close (64 = 256 sources)
 
-    // slice v = wid * H + h of V, in whole 8-source granules; empty slices have v_hi == v_lo (clamped: no wrap-around)
-    const uint32_t v = wid * H + h;
-    const uint32_t nunits = (n0 + 7u) / 8u;
-    const uint32_t per = (nunits + V - 1) / V;
-    const uint32_t u_lo = min(v * per, nunits);
-    const uint32_t u_hi = min(u_lo + per, nunits);
-    const uint32_t v_lo = u_lo * 8u;
-    const uint32_t v_hi = max(min(u_hi * 8u, n0), v_lo);
-    __syncthreads();
+    for (uint32_t t = 0; t < ntiles; t++) {
+        if (t > 0) __syncthreads();   // every lane is done reading the previous tile
+        sxy[tid] = q0;
+        sxy[tid + WAVE * W] = q1;
+        sgm[tid] = m0;
+        sgm[tid + WAVE * W] = m1;
+        if (t + 1 < ntiles) fetch(t + 1);   // lands while this tile is being walked
+        __syncthreads();
 
-    // Four sources per group: two 16-byte reads of positions, one of G*m (lanes of one lane group read the same address,
-    // the groups different ones).  The next group's reads are issued before this group's arithmetic: a lane's slice is a
-    // serial chain, and an LDS round trip (~64+ cycles) per four interactions would otherwise sit on it.
-    uint32_t j = v_lo;
-    const uint32_t groups = (v_hi - v_lo) / 4u;
-    v4f P01 = {0.f, 0.f, 0.f, 0.f}, P23 = {0.f, 0.f, 0.f, 0.f}, G4 = {0.f, 0.f, 0.f, 0.f};
-    if (groups > 0) {
-        P01 = *reinterpret_cast<const v4f *>(&sxy[j]);
-        P23 = *reinterpret_cast<const v4f *>(&sxy[j + 2]);
-        G4 = *reinterpret_cast<const v4f *>(&sgm[j]);
+        // this lane's slice of the tile, in whole 8-source granules; empty slices have v_hi == v_lo (clamped: no wrap-around)
+        const uint32_t n_t = min(T, n0 - t * T);
+        const uint32_t nunits = (n_t + 7u) / 8u;
+        const uint32_t per = (nunits + V - 1) / V;
+        const uint32_t u_lo = min(v * per, nunits);
+        const uint32_t u_hi = min(u_lo + per, nunits);
+        const uint32_t v_lo = u_lo * 8u;
+        const uint32_t v_hi = max(min(u_hi * 8u, n_t), v_lo);
+
+        // Four sources per group: two 16-byte reads of positions, one of G*m (lanes of one lane group read the same
+        // address, the groups different ones).  The next group's reads are issued before this group's arithmetic: a
+        // lane's slice is a serial chain, and an LDS round trip per four interactions would otherwise sit on it.
+        uint32_t j = v_lo;
+        const uint32_t groups = (v_hi - v_lo) / 4u;
+        v4f P01 = {0.f, 0.f, 0.f, 0.f}, P23 = {0.f, 0.f, 0.f, 0.f}, G4 = {0.f, 0.f, 0.f, 0.f};
+        if (groups > 0) {
+            P01 = *reinterpret_cast<const v4f *>(&sxy[j]);
+            P23 = *reinterpret_cast<const v4f *>(&sxy[j + 2]);
+            G4 = *reinterpret_cast<const v4f *>(&sgm[j]);
+        }
+        for (uint32_t g = 0; g < groups; g++) {
+            const v4f A01 = P01, A23 = P23, AG = G4;
+            const uint32_t jn = g + 1 < groups ? j + 4 : j;   // the last group re-reads itself instead of branching
+            P01 = *reinterpret_cast<const v4f *>(&sxy[jn]);
+            P23 = *reinterpret_cast<const v4f *>(&sxy[jn + 2]);
+            G4 = *reinterpret_cast<const v4f *>(&sgm[jn]);
+            interact<1, false>(Rv, f2v{A01[0], A01[1]}, AG[0]);
+            interact<1, false>(Rv, f2v{A01[2], A01[3]}, AG[1]);
+            interact<1, false>(Rv, f2v{A23[0], A23[1]}, AG[2]);
+            interact<1, false>(Rv, f2v{A23[2], A23[3]}, AG[3]);
+            j += 4;
+            if (++open_groups == CHUNK * CLOSE_EVERY / 4) {
+                Rv.close_chunk();
+                open_groups = 0;
+            }
+        }
+        for (; j < v_hi; j++) {
+            const float2 a0 = sxy[j];
+            interact<1, false>(Rv, f2v{a0.x, a0.y}, sgm[j]);
+        }
     }
-    for (uint32_t g = 0; g < groups; g++) {
-        const v4f A01 = P01, A23 = P23, AG = G4;
-        const uint32_t jn = g + 1 < groups ? j + 4 : j;   // the last group re-reads itself instead of branching
-        P01 = *reinterpret_cast<const v4f *>(&sxy[jn]);
-        P23 = *reinterpret_cast<const v4f *>(&sxy[jn + 2]);
-        G4 = *reinterpret_cast<const v4f *>(&sgm[jn]);
-        interact<1, false>(Rv, f2v{A01[0], A01[1]}, AG[0]);
-        interact<1, false>(Rv, f2v{A01[2], A01[3]}, AG[1]);
-        interact<1, false>(Rv, f2v{A23[0], A23[1]}, AG[2]);
-        interact<1, false>(Rv, f2v{A23[2], A23[3]}, AG[3]);
-        j += 4;
-        if (((j - v_lo) & (CHUNK * CLOSE_EVERY - 1)) == 0) Rv.close_chunk();
-    }
-    for (; j < v_hi; j++) {
-        const float2 a0 = sxy[j];
-        interact<1, false>(Rv, f2v{a0.x, a0.y}, sgm[j]);
-    }
-    if ((v_hi - v_lo) & (CHUNK * CLOSE_EVERY - 1)) Rv.close_chunk();
+    Rv.close_chunk();   // whatever is still open (a no-op on exact zeros)
 
     // W x H partial sums per receiver meet in LDS.  Two levels, fixed order: thread (c, r) of the first wave adds the
     // slices [c * V / S, (c + 1) * V / S) of receiver r, then thread r adds those S sums -- 64 dependent adds by 16
-    // threads would be the longest serial chain of a short launch.
+    // threads would be the longest serial chain of a short launch.  Both levels are compensated (Kahan): up to 128
+    // same-signed partial sums added plainly would cost ~V/2 ulps, more than the lanes' own block sums lose.
     partial[v * R + r] = make_float2(Rv.s[0].x, Rv.s[0].y);
     __syncthreads();
     constexpr uint32_t S = WAVE / R;        // = H second-level terms per receiver, computed by the first wave's 64 lanes
     constexpr uint32_t PER = V / S;         // = W slices per first-level sum
+    auto kahan_add = [](float &sum, float &comp, float term) {
+        const float y = __fsub_rn(term, comp);
+        const float t = __fadd_rn(sum, y);
+        comp = __fsub_rn(__fsub_rn(t, sum), y);
+        sum = t;
+    };
     if (wid == 0) {
         const uint32_t c = lane / R, rr = lane % R;
-        float sx = 0.0f, sy = 0.0f;
+        float sx = 0.0f, sy = 0.0f, cx = 0.0f, cy = 0.0f;
 #pragma unroll
         for (uint32_t s2 = 0; s2 < PER; s2++) {
             const float2 t = partial[(c * PER + s2) * R + rr];
-            sx = __fadd_rn(sx, t.x);
-            sy = __fadd_rn(sy, t.y);
+            kahan_add(sx, cx, t.x);
+            kahan_add(sy, cy, t.y);
         }
         // same wave: LDS executes one wave's accesses in order; the fences only stop the compiler from reordering
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -582,12 +614,12 @@ __global__ __launch_bounds__(WAVE *W) void lane_split_kernel(const StepParams p)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane < R) {
-            float ax = 0.0f, ay = 0.0f;
+            float ax = 0.0f, ay = 0.0f, ex = 0.0f, ey = 0.0f;
 #pragma unroll
             for (uint32_t c2 = 0; c2 < S; c2++) {
                 const float2 t = partial[V * R + c2 * R + lane];
-                ax = __fadd_rn(ax, t.x);
-                ay = __fadd_rn(ay, t.y);
+                kahan_add(ax, ex, t.x);
+                kahan_add(ay, ey, t.y);
             }
             finish_receiver(p, blockIdx.x * R + lane, ax, ay, dt);
         }
@@ -860,11 +892,10 @@ int lane_split_rule(uint32_t n_recv, uint32_t n_src, int *w) {
         *w = 8;
         return 4;
     }
-    if (pairs <= 6.0e5) {
+    if (pairs <= 2.5e6) {
         *w = 8;
         return 8;
     }
-    if (pairs <= 2.5e6) return 8;
     return 4;
 }
 
@@ -974,8 +1005,8 @@ dim3 step_grid(LaunchShape s, uint32_t n_recv) {
 
 size_t step_lds_bytes(LaunchShape s, uint32_t n_src) {
     if (s.lanes <= 1) return 0;
-    const size_t pad = ((size_t)n_src + 7u) & ~(size_t)7u;
-    return pad * 12 + ((size_t)s.w + 1) * WAVE * sizeof(float2);   // sources (x, y, G*m) + [w * lanes][64 / lanes] partial sums + 64 second-level sums
+    (void)n_src;   // the sources pass through one tile of 2 * 64 * w entries, whatever their number
+    return (size_t)2 * WAVE * s.w * 12 + ((size_t)s.w + 1) * WAVE * sizeof(float2);   // tile (x, y, G*m) + [w * lanes][64 / lanes] partial sums + 64 second-level sums
 }
 const void *finish_kernel_fn() { return reinterpret_cast<const void *>(&finish_kernel); }
 dim3 finish_grid(uint32_t n_recv) { return dim3((n_recv + 255u) / 256u); }

@@ -29,7 +29,7 @@ for n in [int(x) for x in sys.argv[1:]] or [500, 800, 1200, 2000, 4000, 10000]:
     auto_us, auto_sh = timed(n, m, part, lanes=1)
     rows = []
     for lanes in (2, 4, 8):
-        for wv in (8, 16):
+        for wv in ((4, 8, 16) if lanes < 8 else (8, 16)):
             sim = nb.SimPipeline(n, m); sim.configure(lanes=lanes, w=wv); sim.set_data(part); sim.update(1, 0.01)
             got = sim.get_data(); sh = sim.launch_shape(); sim.close()
             if sh["lanes"] != lanes:
