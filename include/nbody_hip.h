@@ -170,8 +170,8 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
  *               The step size is never baked into a chain: kernels read it from device memory.
  *   "lanes"     lane groups per wave: 2 or 4 = the 64 lanes of a wave are that many groups over the SAME 64 / lanes receivers,
  *               each group walking its own slice of the sources (w x lanes slices per receiver inside one workgroup: the
- *               parallelism of a source split without its second kernel; sources staged once in LDS, k = 1, split = 1,
- *               at most 8192 sources, unsharded whole steps only); 1 = never; 0 (default) = auto: latency-bound launches
+ *               parallelism of a source split without its second kernel; sources staged through LDS tile by tile, k = 1,
+ *               split = 1, unsharded single-pass steps only; also 8); 1 = never; 0 (default) = auto: latency-bound launches
  *               (N x M <= 9e6, about N <= 4 000) whose other shape knobs are on auto -- 15-28 % faster there than the best
  *               split shape (profiles/r03_lane_split_scan.txt)
  *   "fused_chain"  worlds that fit ONE 1024-thread workgroup (N <= 512) can run a whole n-step call inside one launch:

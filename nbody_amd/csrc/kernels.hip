@@ -486,7 +486,7 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
 // source cannot be a wave-uniform scalar operand: the workgroup stages the sources in LDS, tile by tile (2 x 64 x W
 // sources per tile, coalesced loads, fetched into registers one tile ahead), and every lane reads its own slice of the
 // tile -- per-lane data is what LDS is for (cf. "Why the LDS-tile route trails").  K = 1, split = 1, slices in 8-source
-// granules, Kahan block closes every 256 sources a lane has added.
+// granules, Kahan block closes every 128 sources a lane has added.
 template <int W, int H>
 __global__ __launch_bounds__(WAVE *W) void lane_split_kernel(const StepParams p) {
     constexpr uint32_t R = WAVE / H;        // receivers per workgroup
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(WAVE *W) void lane_split_kernel(const StepParams p)
         Rv.r[0] = p.radius[i];
     }
     Rv.clear();
-    uint32_t open_groups = 0;   // groups of four added since the last block close (64 = 256 sources)
+    uint32_t open_groups = 0;   // groups of four added since the last block close
 
     for (uint32_t t = 0; t < ntiles; t++) {
         if (t > 0) __syncthreads();   // every lane is done reading the previous tile
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(WAVE *W) void lane_split_kernel(const StepParams p)
             interact<1, false>(Rv, f2v{A23[0], A23[1]}, AG[2]);
             interact<1, false>(Rv, f2v{A23[2], A23[3]}, AG[3]);
             j += 4;
-            if (++open_groups == CHUNK * CLOSE_EVERY / 4) {
+            if (++open_groups == 32) {   // 128 sources: half the classic kernel's block (K = 1 chains round more often)
                 Rv.close_chunk();
                 open_groups = 0;
             }
@@ -586,26 +586,21 @@ __global__ __launch_bounds__(WAVE *W) void lane_split_kernel(const StepParams p)
 
     // W x H partial sums per receiver meet in LDS.  Two levels, fixed order: thread (c, r) of the first wave adds the
     // slices [c * V / S, (c + 1) * V / S) of receiver r, then thread r adds those S sums -- 64 dependent adds by 16
-    // threads would be the longest serial chain of a short launch.  Both levels are compensated (Kahan): up to 128
-    // same-signed partial sums added plainly would cost ~V/2 ulps, more than the lanes' own block sums lose.
+    // threads would be the longest serial chain of a short launch.  Plain adds, like the classic kernel's sum over its W
+    // slices and split parts (compensating them measured +0.15 us per step at N = 500 ... 2 000 and bought no accuracy:
+    // the error sits in the lanes' own block sums, which is why those close every 128 sources here).
     partial[v * R + r] = make_float2(Rv.s[0].x, Rv.s[0].y);
     __syncthreads();
     constexpr uint32_t S = WAVE / R;        // = H second-level terms per receiver, computed by the first wave's 64 lanes
     constexpr uint32_t PER = V / S;         // = W slices per first-level sum
-    auto kahan_add = [](float &sum, float &comp, float term) {
-        const float y = __fsub_rn(term, comp);
-        const float t = __fadd_rn(sum, y);
-        comp = __fsub_rn(__fsub_rn(t, sum), y);
-        sum = t;
-    };
     if (wid == 0) {
         const uint32_t c = lane / R, rr = lane % R;
-        float sx = 0.0f, sy = 0.0f, cx = 0.0f, cy = 0.0f;
+        float sx = 0.0f, sy = 0.0f;
 #pragma unroll
         for (uint32_t s2 = 0; s2 < PER; s2++) {
             const float2 t = partial[(c * PER + s2) * R + rr];
-            kahan_add(sx, cx, t.x);
-            kahan_add(sy, cy, t.y);
+            sx = __fadd_rn(sx, t.x);
+            sy = __fadd_rn(sy, t.y);
         }
         // same wave: LDS executes one wave's accesses in order; the fences only stop the compiler from reordering
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -614,12 +609,12 @@ __global__ __launch_bounds__(WAVE *W) void lane_split_kernel(const StepParams p)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane < R) {
-            float ax = 0.0f, ay = 0.0f, ex = 0.0f, ey = 0.0f;
+            float ax = 0.0f, ay = 0.0f;
 #pragma unroll
             for (uint32_t c2 = 0; c2 < S; c2++) {
                 const float2 t = partial[V * R + c2 * R + lane];
-                kahan_add(ax, ex, t.x);
-                kahan_add(ay, ey, t.y);
+                ax = __fadd_rn(ax, t.x);
+                ay = __fadd_rn(ay, t.y);
             }
             finish_receiver(p, blockIdx.x * R + lane, ax, ay, dt);
         }
