@@ -168,10 +168,10 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
  *               with plain launches for the remainder; on larger worlds a chain length runs as plain launches the first
  *               time it is asked for and as a cached hipGraph from the second time on (a replay saves nothing there).
  *               The step size is never baked into a chain: kernels read it from device memory.
- *   "lanes"     lane groups per wave: 2 or 4 = the 64 lanes of a wave are that many groups over the SAME 64 / lanes receivers,
+ *   "lanes"     lane groups per wave: 2, 4 or 8 = the 64 lanes of a wave are that many groups over the SAME 64 / lanes receivers,
  *               each group walking its own slice of the sources (w x lanes slices per receiver inside one workgroup: the
  *               parallelism of a source split without its second kernel; sources staged through LDS tile by tile, k = 1,
- *               split = 1, unsharded single-pass steps only; also 8); 1 = never; 0 (default) = auto: latency-bound launches
+ *               split = 1, unsharded single-pass steps only); 1 = never; 0 (default) = auto: latency-bound launches
  *               (N x M <= 9e6, about N <= 4 000) whose other shape knobs are on auto -- 15-28 % faster there than the best
  *               split shape (profiles/r03_lane_split_scan.txt)
  *   "fused_chain"  worlds that fit ONE 1024-thread workgroup (N <= 512) can run a whole n-step call inside one launch:
@@ -203,7 +203,7 @@ int nb_hip_configure(SimPipeline *sim, const char *key, int value);
 /* Steps of the last PerformSimUpdate / nb_hip_step_async that ran inside one-workgroup chain launches ("fused_chain"). */
 uint32_t nb_hip_last_fused_steps(const SimPipeline *sim);
 
-/* Lane groups per wave of the last step launch ("lanes" knob): 1, 2 or 4. */
+/* Lane groups per wave of the last step launch ("lanes" knob): 1, 2, 4 or 8. */
 int nb_hip_launch_lanes(const SimPipeline *sim);
 
 /* What the last step launch actually used (after "auto"): fills k, w, variant, split, workgroups. */

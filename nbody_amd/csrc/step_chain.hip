@@ -66,20 +66,9 @@ nb::LaunchShape resolve_shape(SimPipeline *s) {
     memset(&probe, 0, sizeof probe);
     probe.src_end[0] = s->n_src;
     const uint32_t passes = (s->sharded && s->overlap) ? 1 : passes_for(s, probe);
-    // lane-split shapes stage ALL sources of the launch in LDS and walk one source range: whole unsharded steps only
+    // lane-split launches walk ONE source range of an unsharded pipeline (one launch = the whole step)
     if (s->sharded || passes != 1 || s->n_src > nb::LANE_SPLIT_MAX_SRC || s->n_src == 0) want.lanes = 1;   // never, not "auto"
     nb::LaunchShape sh = nb::choose_shape(want, s->n_real, (s->n_src + passes - 1) / passes, g_dev.compute_units);
-    if (sh.lanes > 1) {
-        // the kernels may need more than the 64 KB of dynamic LDS a launch gets by default: raise the limit once per kernel
-        static std::vector<const void *> raised;
-        const void *fn = nb::step_kernel_fn(sh);
-        bool done = false;
-        for (const void *f : raised) done = done || f == fn;
-        if (!done && fn) {
-            ASSERT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "raise the dynamic LDS limit");
-            raised.push_back(fn);
-        }
-    }
     NB_ASSERT(nb::step_kernel_fn(sh) != nullptr, "no step kernel for k=%d w=%d variant=%d", sh.k, sh.w, sh.variant);
     if (sh.split > 1) {
         const size_t need = (size_t)sh.split * s->n_real;
