@@ -917,6 +917,8 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
         LaunchShape sh = want;
         sh.k = 1;
         sh.w = (want.w == 4 || want.w == 8 || want.w == 16) ? want.w : 16;
+        if (sh.lanes == 8 && sh.w == 4) sh.w = 8;   // eight groups: instantiated for 8 and 16 waves
+        if (sh.lanes != 2 && sh.lanes != 4 && sh.lanes != 8) sh.lanes = 4;
         sh.split = 1;
         sh.unit = 8;
         sh.variant = VARIANT_LDS;

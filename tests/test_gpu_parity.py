@@ -762,8 +762,9 @@ def test_random_small_worlds(seed):
 @pytest.mark.parametrize("block", range(4))
 def test_random_worlds_random_knobs(block):
     """Seeded fuzz over world sizes, massive fractions and every launch knob (receivers per lane, waves per workgroup,
-    source split, slice granule, source passes, source route, graph policy): one step must sit within the float64
-    tolerance with an exact integrator, and a three-step chain must give the same bytes as plain launches."""
+    source split, slice granule, source passes, source route, lane groups, one-workgroup chain, graph policy): one step
+    must sit within the float64 tolerance with an exact integrator, and a three-step chain must give the same bytes as
+    plain launches."""
     rng = np.random.default_rng(9000 + block)
     for case in range(12):
         n = int(rng.choice([1, 2, 63, 64, 65, 127, 300, 777, 1024, 1500, 2111, 3000]))
@@ -771,7 +772,8 @@ def test_random_worlds_random_knobs(block):
         part, m = synth(n, frac, seed=int(rng.integers(1 << 30)), extent=float(rng.choice([1e2, 1e4, 1e6])))
         knobs = dict(k=int(rng.choice([0, 1, 2])), w=int(rng.choice([0, 1, 4, 8, 16])), split=int(rng.integers(0, 17)),
                      unit=int(rng.choice([0, 8, 16, 32, 64])), passes=int(rng.choice([0, 1, 2, 3])),
-                     variant=int(rng.choice([0, 1])))
+                     variant=int(rng.choice([0, 1])), lanes=int(rng.choice([0, 0, 1, 2, 4, 8])),
+                     fused_chain=int(rng.choice([0, 1, 2])))
         dt = float(rng.choice([0.01, 0.005, 0.02]))
         one = run(part, m, 1, dt, **knobs)
         acc64, mag = ob.acc_f64(part, m)
