@@ -530,6 +530,13 @@ __global__ __launch_bounds__(WAVE *W) void lane_split_kernel(const StepParams p)
         Rv.r[0] = p.radius[i];
     }
     Rv.clear();
+    // The integrating threads (first wave, lanes < R: lane == r there, so Rv.p IS their receiver's position) fetch the
+    // velocity now: behind the reduction it would be one more memory round trip (~0.3 us of a ~3 us step) on the
+    // critical path of a launch that is nothing but latency.
+    const uint32_t my_logical = blockIdx.x * R + lane;
+    const bool integrates = wid == 0 && lane < R && my_logical < p.n_recv && p.flags == 0;
+    float2 vel0 = make_float2(0.f, 0.f);
+    if (integrates) vel0 = p.vel[receiver_slot(p, my_logical)];
     uint32_t open_groups = 0;   // groups of four added since the last block close
 
     for (uint32_t t = 0; t < ntiles; t++) {
@@ -616,7 +623,23 @@ __global__ __launch_bounds__(WAVE *W) void lane_split_kernel(const StepParams p)
                 ax = __fadd_rn(ax, t.x);
                 ay = __fadd_rn(ay, t.y);
             }
-            finish_receiver(p, blockIdx.x * R + lane, ax, ay, dt);
+            if (integrates) {
+                // finish_receiver with everything it reads already in registers: acc, then the reference's integrator
+                // roundings (vel += acc*dt; pos += vel*dt; sim_cpu.c:191-193)
+                const uint32_t i = receiver_slot(p, my_logical);
+                p.acc[i] = make_float2(ax, ay);
+                float2 vv = vel0;
+                vv.x = __fadd_rn(vv.x, __fmul_rn(ax, dt));
+                vv.y = __fadd_rn(vv.y, __fmul_rn(ay, dt));
+                float2 q = make_float2(Rv.p[0].x, Rv.p[0].y);
+                q.x = __fadd_rn(q.x, __fmul_rn(vv.x, dt));
+                q.y = __fadd_rn(q.y, __fmul_rn(vv.y, dt));
+                p.vel[i] = vv;
+                p.pos_out[i] = q;
+                if (i < p.n_mirror) p.mirror[i] = q;
+            } else {
+                finish_receiver(p, my_logical, ax, ay, dt);   // chained passes (flags): the general epilogue
+            }
         }
     }
 }

@@ -11,15 +11,28 @@ import sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 PROF = os.path.join(ROOT, "gpurun_out", "prof_mid")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+suffix = sys.argv[2] if len(sys.argv) > 2 else "mid_n_pmc"   # output: profiles/<tag>_<suffix>.txt
+sizes = sys.argv[3] if len(sys.argv) > 3 else "--n 10000 --n 20000 --n 50000"
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(PROF, "pmc_*", "*", "*_counter_collection.csv")):
+
+
+def newest(pattern):
+    best = {}
+    for f in glob.glob(pattern):
+        d = os.path.dirname(f)
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
+
+
+for f in newest(os.path.join(PROF, "pmc_*", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        short = "step_kernel" + name.split("step_kernel")[1].split("E")[0] if "step_kernel" in name else name.split("(")[0][-28:]
+        short = name.split("(anonymous namespace)::")[-1].split("(")[0]
         key = (short, int(r["Grid_Size"]), int(r["Workgroup_Size"]))
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
         agg[key]["_dur_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-lines = ["== rocprofv3 --pmc SQ_* / GRBM_* --kernel-trace -- nbody-bench --gpu --n 10000 --n 20000 --n 50000 --steps 100 --warmup 10 --dt 0.01 ==",
+lines = [f"== rocprofv3 --pmc SQ_* / GRBM_* --kernel-trace -- nbody-bench --gpu {sizes} --steps 100 --warmup 10 --dt 0.01 ==",
          "(per kernel launch, mean over the launches of that grid; SQ_*_CYCLES and SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles summed over waves)"]
 for key in sorted(agg, key=lambda k: (k[1], k[0])):
     c = {k: sum(v) / len(v) for k, v in agg[key].items()}
@@ -41,12 +54,12 @@ for key in sorted(agg, key=lambda k: (k[1], k[0])):
         simd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * 1024
         lines.append(f"    -> VALU issue utilisation over the kernel's active time (SQ_INSTS_VALU * 26/10 / SIMD-cycles): "
                      f"{c['SQ_INSTS_VALU'] * 26 / 10 / simd_cycles:.2f}")
-stats = glob.glob(os.path.join(PROF, "stats", "*", "*_kernel_stats.csv"))
+stats = newest(os.path.join(PROF, "stats", "*", "*_kernel_stats.csv"))
 if stats:
     lines.append("")
     lines.append("== rocprofv3 --kernel-trace --stats (same command) ==")
     for r in csv.DictReader(open(stats[0])):
         lines.append(f"{r['Name'][:80]:80s} calls={r['Calls']:>5s} avg_ns={float(r['AverageNs']):12.0f} pct={float(r['Percentage']):6.2f}")
 text = "\n".join(lines) + "\n"
-open(os.path.join(ROOT, "profiles", f"{tag}_mid_n_pmc.txt"), "w").write(text)
+open(os.path.join(ROOT, "profiles", f"{tag}_{suffix}.txt"), "w").write(text)
 print(text)
