@@ -154,6 +154,27 @@ def test_launch_plan_round_boundaries_and_splits():
     assert nb.plan_launch(1 << 20, 523884, compute_units=0)["k"] == 2                       # 0 CUs -> default 256
 
 
+def test_lane_split_rule_matches_the_committed_scan():
+    """nb_hip_plan_launch_lanes: latency-bound unsharded steps (N x M <= 9e6) run as lane-split launches -- (lanes, w) read
+    off profiles/r03_lane_split_scan.txt -- and nothing above that does (the scheme loses once a step is throughput)."""
+    want = {(250, 119): (4, 8), (500, 244): (4, 8), (800, 386): (8, 8), (1200, 586): (8, 8), (2000, 967): (8, 8),
+            (3000, 1467): (4, 16), (4000, 1937): (4, 16)}
+    for (n, m), (lanes, w) in want.items():
+        p = nb.plan_launch(n, m)
+        assert (p["lanes"], p["lanes_w"]) == (lanes, w), (n, m, p)
+    for n, m in ((5000, 2439), (10000, 4917), (20000, 9956), (65536, 32641), (1 << 20, 523884), (100, 0), (0, 0)):
+        assert nb.plan_launch(n, m)["lanes"] == 1, (n, m)
+    # the committed scan really says so: at every scanned size up to N = 4 000 some lane-split shape beats the classic
+    # auto shape, and from N = 5 000 on none does
+    import re
+    text = open(os.path.join(ROOT, "profiles", "r03_lane_split_scan.txt")).read()
+    block = text[text.index("== the shipped (tiled) kernel"):text.index("== the shipped kernel (velocity")]
+    rows = re.findall(r"^N=\s*(\d+) M=\s*\d+: auto\s+([\d.]+) us .*?\| lanes=\d+ w=\d+:\s+([\d.]+) us", block, re.M)
+    assert len(rows) >= 10
+    for n, auto_us, best_us in rows:
+        assert (float(best_us) < float(auto_us)) == (int(n) <= 4000 or int(n) == 6000), (n, auto_us, best_us)
+
+
 def test_gpu_call_without_gpu_aborts_loudly():
     """No CPU fallback: UpdateWorld_GPU on a box without a GPU must abort, not compute."""
     if nb.device_count() > 0:
