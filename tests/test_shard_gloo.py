@@ -117,3 +117,36 @@ def test_bench_last_gasp_line_on_a_fatal_signal():
     code2 = code.replace("ctypes.CDLL(None).abort()", "g.disarm(); ctypes.CDLL(None).abort()")
     r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=120)
     assert r.returncode == 6 and r.stdout == ""
+
+
+def test_bench_leg_guard_deadline_writes_the_line_and_exits():
+    """bench.py's LegGuard without a GPU: a leg that outlives its deadline makes rank 0 write what is in hand with
+    "extras_aborted" and leave with exit code 4; other ranks leave with 4 and write nothing; a disarmed guard stays quiet."""
+    import json
+    import textwrap
+    root = os.path.dirname(HERE)
+    code = textwrap.dedent(f'''
+        import json, os, sys, time
+        sys.path.insert(0, {root!r})
+        import bench
+        rank = int(sys.argv[1])
+        out = {{"value": 123.0, "self_check": {{"ranks_agree": True}}, "extra_configs": []}}
+        def emit(leg):
+            os.write(1, (json.dumps(dict(out, extras_aborted=leg)) + "\\n").encode())
+        g = bench.LegGuard(rank, emit, default_s=0.5)
+        g.arm("fast")
+        g.disarm()
+        time.sleep(1.0)                 # disarmed: nothing may fire
+        g.arm("overlap")
+        time.sleep(30)                  # "stuck in a C call"
+        print("NOT REACHED")
+    ''')
+    t0 = __import__("time").time()
+    r0 = subprocess.run([sys.executable, "-c", code, "0"], capture_output=True, text=True, timeout=120)
+    assert r0.returncode == 4 and __import__("time").time() - t0 < 20
+    lines = r0.stdout.splitlines()
+    assert len(lines) == 1 and json.loads(lines[0]) == {"value": 123.0, "self_check": {"ranks_agree": True},
+                                                         "extra_configs": [], "extras_aborted": "overlap"}
+    assert "passed its deadline" in r0.stderr
+    r1 = subprocess.run([sys.executable, "-c", code, "1"], capture_output=True, text=True, timeout=120)
+    assert r1.returncode == 4 and r1.stdout == ""
