@@ -785,6 +785,24 @@ def test_random_worlds_random_knobs(block):
         assert run(part, m, 3, dt, graph=1, **knobs).tobytes() == run(part, m, 3, dt, graph=0, **knobs).tobytes(), (n, knobs)
 
 
+def test_receivers_are_independent_of_each_other():
+    """A receiver's new state depends on the sources and on itself, never on which other receivers exist (reference
+    particle_cs.glsl:32-54: each invocation reads all sources and writes only its own particle).  With one wave walking
+    all sources in index order (w = 1) that holds bit for bit: appending massless receivers, or dropping some, leaves
+    every other particle's result untouched -- on the classic kernel and, with the slicing fixed by the source count
+    alone, on the lane-split one."""
+    part, m = synth(900, 0.4, seed=77)
+    extra, _ = synth(300, 0.0, seed=78)             # massless only
+    bigger = np.concatenate([part, extra])
+    fewer = part[: m + 100]
+    for knobs in (dict(k=1, w=1), dict(k=2, w=1), dict(lanes=4, w=8), dict(lanes=8, w=16)):
+        base = run(part, m, 2, 0.01, **knobs)
+        more = run(bigger, m, 2, 0.01, **knobs)
+        less = run(fewer, m, 2, 0.01, **knobs)
+        assert more[:900].tobytes() == base.tobytes(), knobs
+        assert less.tobytes() == base[: m + 100].tobytes(), knobs
+
+
 def test_negative_mass_is_massless():
     a = np.zeros((3, 8), dtype=np.float32)
     a[:, 7] = 1.0
