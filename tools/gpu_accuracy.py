@@ -15,7 +15,8 @@ for n in [int(x) for x in sys.argv[1:]] or (4096, 65536, 262144, 1 << 20):
     acc64, mag = ob.acc_f64_subset(part, m, idx)
     avx = ob.acc_avx_subset(part, m, idx).astype(np.float64)
     e_avx = np.abs(avx - acc64)
-    for knobs in (dict(), dict(w=1, k=1), dict(variant=0)):   # auto shape (scalar-cache route), one wave per tile, LDS route
+    # every knob on auto (lane-split below N x M = 9e6), the classic auto shape, one wave per tile, the LDS-tile route
+    for knobs in (dict(), dict(lanes=1), dict(w=1, k=1), dict(variant=0)):
         sim = nb.SimPipeline(n, m); sim.configure(**knobs); sim.set_data(part); sim.update(1, 0.01)
         got = sim.get_data()[idx, 4:6].astype(np.float64); shape = sim.launch_shape(); sim.close()
         e = np.abs(got - acc64)
