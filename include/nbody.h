@@ -96,6 +96,22 @@ void UpdateWorld_GPU(World *w, float dt, uint32_t n);
  */
 World *CreateWorldSharded(const Particle *ps, uint32_t size, int rank, int nranks, const void *unique_id128);
 
+/*
+ * Extension: the same sharded World over a caller-supplied host transport instead of RCCL -- an in-place all-gather
+ * over host memory (buf holds nranks slots of bytes_per_rank bytes; slot `rank` is filled on entry, every slot on
+ * return; see CreateSimPipelineShardedWith in include/nbody_hip.h).  This is how nbody-bench --gpus P --transport shm
+ * steps P real processes on ONE GPU, where RCCL refuses duplicate devices.
+ */
+typedef void (*NbAllGatherFn)(void *ctx, void *buf, uint64_t bytes_per_rank, int rank, int nranks);
+World *CreateWorldShardedWith(const Particle *ps, uint32_t size, int rank, int nranks, NbAllGatherFn allgather, void *ctx);
+
+/*
+ * Extension: the HIP pipeline behind a World (include/nbody_hip.h), for tooling that wants its knobs and timers
+ * (nb_hip_configure, nb_hip_last_step_ms, nb_hip_comm_info ...).  Owned by the World; never destroy it.
+ */
+typedef struct SimPipeline SimPipeline;
+SimPipeline *GetWorldPipeline(World *w);
+
 #ifdef __cplusplus
 }
 #endif

@@ -254,7 +254,7 @@ SimPipeline *CreateSimPipelineSharded(WorldData data, int rank, int nranks, cons
  * ranks on a device).  Everything else -- shard plan, kernels, mirror / gather layout, overlap mode -- is the RCCL
  * path's; "sharded_graph" is ignored (a host callback cannot run inside a captured graph).
  */
-typedef void (*NbAllGatherFn)(void *ctx, void *buf, uint64_t bytes_per_rank, int rank, int nranks);
+/* NbAllGatherFn: include/nbody.h -- void (*)(void *ctx, void *buf, uint64_t bytes_per_rank, int rank, int nranks) */
 SimPipeline *CreateSimPipelineShardedWith(WorldData data, int rank, int nranks, NbAllGatherFn allgather, void *ctx);
 
 /* The shard arithmetic, pure host code (usable without a GPU). */

@@ -93,6 +93,8 @@ NBODY_API = {
     "UpdateWorld_CPU": (None, [C.c_void_p, C.c_float, C.c_uint32]),
     "UpdateWorld_GPU": (None, [C.c_void_p, C.c_float, C.c_uint32]),
     "CreateWorldSharded": (C.c_void_p, [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
+    "CreateWorldShardedWith": (C.c_void_p, [C.c_void_p, C.c_uint32, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]),
+    "GetWorldPipeline": (C.c_void_p, [C.c_void_p]),
     "MakeGalaxies": (C.c_void_p, [C.c_uint32, C.c_uint32]),
     "MakeGalaxiesSeeded": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_uint64]),
 }

@@ -27,18 +27,45 @@
  *               profiles/r01_ubench6_launch_floor.txt; a step is 1 kernel, or 2 when the sources are split)
  *   %floor    = floor / measured: how close the step is to that bound.  Below N ~ 50 000 a launch cannot fill the
  *               chip for long enough to amortise its latencies; the reference's SIZES[] (bench.c:38) all live there.
- * Several GPUs are driven one process per GPU (bench.py under torch.distributed.run, include/nbody_hip.h part 2),
- * not from this single-process harness.
+ *
+ * Several GPUs (SURVEY.md section 8f rank 1 `--gpus`, 8e): one process per GPU, host code in C, no Python, no torch.
+ *   --gpus P           fork P ranks BEFORE anything touches HIP; rank r drives device r; the ranks share one
+ *                      anonymous MAP_SHARED page (rank_page.h) for barriers, the max-over-ranks time and RCCL's unique id
+ *   --transport T      rccl (default): CreateWorldSharded, per-step in-place ncclAllGather over xGMI inside the library;
+ *                      shm: CreateWorldShardedWith over the shared page (host-staged) -- lets P ranks share ONE GPU, where
+ *                      RCCL refuses duplicate devices, to exercise the whole multi-process path on a one-GPU box
+ *   --modes a,b,..     rows per size: plain (kernel, then gather in-stream), overlap (own-shard kernel runs while the
+ *                      other shards' positions arrive), graph (the {kernel, all-gather} x K chain captured as a
+ *                      hipGraph; rccl only).  Default: all the transport allows
+ *   --verify K         before timing, K steps of every mode on a fresh sharded World: every rank must hold the same
+ *                      bytes, and rank 0 compares them with an ordinary single-GPU World stepped the same way
+ *                      (default 3; 0 = skip).  A deviation above 1e-5 relative L2 in positions fails the run.
+ *                      Without --gpus (and with both backends): K steps of UpdateWorld_GPU against K steps of
+ *                      UpdateWorld_CPU per row, relative to what the steps moved; above 1e-4 the run fails
+ *   --force-sharded    with --gpus 1: still go through the RCCL path (one-rank communicator)
+ *   --wait-timeout S   how long a rank waits for the others at the page before it gives up (default 180)
+ *   --selftest-ranks   no GPU: P ranks exercise the page only (barriers, id hand-over, reductions, all-gathers)
+ * Rank 0 prints the table: N, ranks, mode, us/step (max over ranks, barrier on both sides of ONE UpdateWorld_GPU(K) call),
+ * steps/s, interactions/s, % of P x 157.3 TFLOP/s, and the per-step device time of the kernels and of the all-gathers
+ * (nb_hip_last_step_breakdown; 0 for graph rows).  A rank that fails exits non-zero; the parent reaps every child, ends
+ * the stragglers (exact pids) and reports -- it never re-executes anything.
  */
+#define _GNU_SOURCE
+#include <signal.h>
 #include <stdbool.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/types.h>
+#include <sys/wait.h>
 #include <time.h>
+#include <unistd.h>
 
 #include <galaxy.h>
 #include <nbody.h>
 #include <nbody_hip.h>
+
+#include "rank_page.h"
 
 #define CALIBRATION_N 100000u     /* the last row of the reference's table (bench.c:38): the large-N rate is measured there */
 #define LAUNCH_FLOOR_US 1.7       /* per dependent kernel inside a hipGraph (profiles/r01_ubench6_launch_floor.txt) */
@@ -93,93 +120,97 @@ static double measure_large_n_rate(void) {
 
 static const uint32_t REFERENCE_SIZES[] = {250, 500, 800, 1200, 2000, 4000, 10000, 20000, 50000, 100000};
 
-int main(int argc, char **argv) {
-    bool use_cpu = true, use_gpu = true;
+enum { MODE_PLAIN = 0, MODE_OVERLAP = 1, MODE_GRAPH = 2, MODE_COUNT = 3 };
+static const char *const MODE_NAME[MODE_COUNT] = {"plain", "overlap", "graph"};
+
+typedef struct Options {
+    bool use_cpu, use_gpu, own_rng, transport_shm, force_sharded, selftest_ranks, verify_given;
     uint32_t sizes[64];
-    uint32_t n_sizes = 0;
-    uint32_t steps = 100, warmup = 10, galaxies = 2, repeats = 1;
-    unsigned seed = 11037;
-    bool own_rng = false;
-    float dt = 1.f;
-    double floor_rate = 0.0; /* 0: measure it */
+    uint32_t n_sizes, steps, warmup, galaxies, repeats, verify_steps;
+    unsigned seed;
+    float dt;
+    double floor_rate; /* 0: measure it */
+    int gpus;
+    int modes[8];
+    int n_modes;
+    double wait_timeout_s;
+    int selftest_die; /* --selftest-die R: that rank leaves with status 7 mid-run (the parent's reaping is what is tested) */
+} Options;
 
-    for (int a = 1; a < argc; a++) {
-        const char *arg = argv[a];
-        const char *val = a + 1 < argc ? argv[a + 1] : NULL;
-        if (!strcmp(arg, "--cpu")) {
-            use_gpu = false;
-        } else if (!strcmp(arg, "--gpu")) {
-            use_cpu = false;
-        } else if (!strcmp(arg, "--n") && val && n_sizes < 64) {
-            sizes[n_sizes++] = (uint32_t)strtoul(val, NULL, 0), a++;
-        } else if (!strcmp(arg, "--steps") && val) {
-            steps = (uint32_t)strtoul(val, NULL, 0), a++;
-        } else if (!strcmp(arg, "--warmup") && val) {
-            warmup = (uint32_t)strtoul(val, NULL, 0), a++;
-        } else if (!strcmp(arg, "--dt") && val) {
-            dt = strtof(val, NULL), a++;
-        } else if (!strcmp(arg, "--galaxies") && val) {
-            galaxies = (uint32_t)strtoul(val, NULL, 0), a++;
-        } else if (!strcmp(arg, "--seed") && val) {
-            seed = (unsigned)strtoul(val, NULL, 0), a++;
-        } else if (!strcmp(arg, "--repeats") && val) {
-            repeats = (uint32_t)strtoul(val, NULL, 0), a++;
-        } else if (!strcmp(arg, "--floor-rate") && val) {
-            floor_rate = strtod(val, NULL), a++;
-        } else if (!strcmp(arg, "--own-rng")) {
-            own_rng = true;
-        } else {
-            fprintf(stderr,
-                    "usage: %s [--cpu|--gpu] [--n N]... [--steps K] [--warmup W] [--dt DT] [--galaxies G] [--seed S]"
-                    " [--own-rng] [--repeats R] [--floor-rate INT_PER_S]\n",
-                    argv[0]);
-            return 2;
-        }
-    }
-    if (n_sizes == 0) {
-        n_sizes = sizeof REFERENCE_SIZES / sizeof REFERENCE_SIZES[0];
-        memcpy(sizes, REFERENCE_SIZES, sizeof REFERENCE_SIZES);
-    }
-    if (steps == 0) steps = 1;
-    if (repeats == 0) repeats = 1;
+static Particle *make_universe(const Options *o, uint32_t n, uint32_t row) {
+    return o->own_rng ? MakeGalaxiesSeeded(n, o->galaxies, o->seed + row) : MakeGalaxies(n, o->galaxies);
+}
 
-    if (use_gpu && floor_rate <= 0.0) {
+/* ---- one process, one GPU: the reference's table ------------------------------------------------------------------ */
+
+/* --verify K with both backends: the same universe stepped K times by UpdateWorld_CPU (the reference AVX path's bits)
+ * and by UpdateWorld_GPU, compared relative to what the steps moved: |dpos_gpu - dpos_cpu| / |dpos_cpu| (L2 over all
+ * particles).  The stated multi-step tolerance is 1e-4; beyond it the run fails. */
+static int verify_backends(const Options *o, const Particle *ps, uint32_t n) {
+    World *c = CreateWorld(ps, n), *g = CreateWorld(ps, n);
+    Particle *start = (Particle *)malloc((size_t)(n ? n : 1) * sizeof(Particle));
+    memcpy(start, GetWorldParticles(c, NULL), (size_t)n * sizeof(Particle));
+    UpdateWorld_CPU(c, o->dt, o->verify_steps);
+    UpdateWorld_GPU(g, o->dt, o->verify_steps);
+    const Particle *pc = GetWorldParticles(c, NULL), *pg = GetWorldParticles(g, NULL);
+    double num = 0.0, den = 0.0;
+    int statics = 1;
+    for (uint32_t i = 0; i < n; i++) {
+        const double cx = (double)pc[i].pos.x - (double)start[i].pos.x, cy = (double)pc[i].pos.y - (double)start[i].pos.y;
+        const double gx = (double)pg[i].pos.x - (double)start[i].pos.x, gy = (double)pg[i].pos.y - (double)start[i].pos.y;
+        num += (gx - cx) * (gx - cx) + (gy - cy) * (gy - cy);
+        den += cx * cx + cy * cy;
+        statics = statics && pc[i].mass == pg[i].mass && pc[i].radius == pg[i].radius;
+    }
+    const double rel = den > 0.0 ? sqrt(num / den) : sqrt(num);
+    fprintf(stderr, "nbody-bench: verify N=%u steps=%u dt=%g: GPU vs CPU rel_displacement %.3e (tolerance 1e-4); mass/radius equal %s\n", n,
+            o->verify_steps, (double)o->dt, rel, statics ? "yes" : "NO");
+    free(start);
+    DestroyWorld(c);
+    DestroyWorld(g);
+    return !(rel <= 1e-4) || !statics;
+}
+
+static int run_single(const Options *o) {
+    int bad = 0;
+    double floor_rate = o->floor_rate;
+    if (o->use_gpu && floor_rate <= 0.0) {
         floor_rate = measure_large_n_rate();
         fprintf(stderr, "nbody-bench: floor rate %.3e interactions/s (measured at N = %u on this box)\n", floor_rate, CALIBRATION_N);
     }
 
-    srand(seed); /* one seed for the whole table, as the reference */
+    srand(o->seed); /* one seed for the whole table, as the reference */
 
     printf("\t      N");
-    if (use_cpu) printf("\t    CPU");
-    if (use_gpu) printf("\t    GPU");
-    if (use_cpu) printf("\t  CPU int/s");
-    if (use_gpu) printf("\t  GPU int/s\t GPU %%peak\t  GPU us\tfloor us\t   %%floor");
+    if (o->use_cpu) printf("\t    CPU");
+    if (o->use_gpu) printf("\t    GPU");
+    if (o->use_cpu) printf("\t  CPU int/s");
+    if (o->use_gpu) printf("\t  GPU int/s\t GPU %%peak\t  GPU us\tfloor us\t   %%floor");
     printf("\n");
 
-    for (uint32_t s = 0; s < n_sizes; s++) {
-        const uint32_t n = sizes[s];
-        Particle *ps = own_rng ? MakeGalaxiesSeeded(n, galaxies, seed + s) : MakeGalaxies(n, galaxies);
+    for (uint32_t s = 0; s < o->n_sizes; s++) {
+        const uint32_t n = o->sizes[s];
+        Particle *ps = make_universe(o, n, s);
         const double pairs = (double)n * (double)count_massive(ps, n);
 
         double cpu_s = 0, gpu_s = 0;
-        if (use_cpu) {
+        if (o->use_cpu) {
             World *w = CreateWorld(ps, n);
-            cpu_s = time_backend(w, UpdateWorld_CPU, dt, warmup, steps, repeats);
+            cpu_s = time_backend(w, UpdateWorld_CPU, o->dt, o->warmup, o->steps, o->repeats);
             DestroyWorld(w);
         }
-        if (use_gpu) {
+        if (o->use_gpu) {
             World *w = CreateWorld(ps, n);
-            gpu_s = time_backend(w, UpdateWorld_GPU, dt, warmup, steps, repeats);
+            gpu_s = time_backend(w, UpdateWorld_GPU, o->dt, o->warmup, o->steps, o->repeats);
             DestroyWorld(w);
         }
         printf("\t%7u", n);
-        if (use_cpu) printf("\t%7ld", (long)(cpu_s * 1e6));
-        if (use_gpu) printf("\t%7ld", (long)(gpu_s * 1e6));
-        if (use_cpu) printf("\t%11.3e", pairs / cpu_s);
+        if (o->use_cpu) printf("\t%7ld", (long)(cpu_s * 1e6));
+        if (o->use_gpu) printf("\t%7ld", (long)(gpu_s * 1e6));
+        if (o->use_cpu) printf("\t%11.3e", pairs / cpu_s);
         /* roofline column: 14 flop per interaction (reference op count, sim_cpu.c:169-188) against the
          * MI355X fp32 vector peak of 157.3 TFLOP/s -- the same convention as bench.py */
-        if (use_gpu) {
+        if (o->use_gpu) {
             int k = 0, wv = 0, split = 1;
             uint32_t groups = 0;
             const uint32_t m = count_massive(ps, n);
@@ -195,7 +226,352 @@ int main(int argc, char **argv) {
         }
         printf("\n");
         fflush(stdout);
+        if (o->use_cpu && o->use_gpu && o->verify_given && o->verify_steps > 0) bad = verify_backends(o, ps, n) || bad;
         free(ps);
     }
-    return 0;
+    return bad;
+}
+
+/* ---- P processes, one per GPU --------------------------------------------------------------------------------------- */
+
+static uint64_t fnv1a(const void *data, size_t bytes) {
+    const unsigned char *p = (const unsigned char *)data;
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < bytes; i++) h = (h ^ p[i]) * 0x100000001b3ull;
+    return h;
+}
+
+static World *make_sharded_world(const Options *o, NbRankPage *pg, const Particle *ps, uint32_t n) {
+    const int rank = nb_rank_page_rank(pg), P = nb_rank_page_nranks(pg);
+    if (o->transport_shm) return CreateWorldShardedWith(ps, n, rank, P, nb_rank_allgather, pg);
+    unsigned char id[NB_HIP_UNIQUE_ID_BYTES];
+    memset(id, 0, sizeof id);
+    if (rank == 0) nb_hip_comm_unique_id(id); /* one id per communicator: a fresh one for every World */
+    nb_rank_share_id(pg, id);
+    return CreateWorldSharded(ps, n, rank, P, id);
+}
+
+static void set_mode(World *w, int mode) {
+    SimPipeline *sim = GetWorldPipeline(w);
+    nb_hip_configure(sim, "overlap", mode == MODE_OVERLAP);
+    nb_hip_configure(sim, "sharded_graph", mode == MODE_GRAPH);
+}
+
+/* K steps of every mode on a fresh sharded World against an ordinary single-GPU World on rank 0; returns 0 when the
+ * ranks agree bit for bit and the positions stay within 1e-5 relative L2 of the single-GPU ones */
+static int verify_row(const Options *o, NbRankPage *pg, const Particle *ps, uint32_t n) {
+    const int rank = nb_rank_page_rank(pg);
+    World *w = make_sharded_world(o, pg, ps, n);
+    World *one = rank == 0 ? CreateWorld(ps, n) : NULL;
+    int bad = 0;
+    for (int mi = 0; mi < o->n_modes; mi++) {
+        set_mode(w, o->modes[mi]);
+        UpdateWorld_GPU(w, o->dt, o->verify_steps);
+        uint32_t got_n = 0;
+        const Particle *got = GetWorldParticles(w, &got_n); /* collective: the full array on every rank */
+        const int agree = nb_rank_all_equal(pg, fnv1a(got, (size_t)got_n * sizeof(Particle)));
+        double rel = 0.0, worst = 0.0;
+        int bitwise = 0;
+        if (rank == 0) {
+            UpdateWorld_GPU(one, o->dt, o->verify_steps);
+            const Particle *want = GetWorldParticles(one, NULL);
+            double num = 0.0, den = 0.0;
+            for (uint32_t i = 0; i < n; i++) {
+                const double dx = (double)got[i].pos.x - (double)want[i].pos.x, dy = (double)got[i].pos.y - (double)want[i].pos.y;
+                num += dx * dx + dy * dy;
+                den += (double)want[i].pos.x * (double)want[i].pos.x + (double)want[i].pos.y * (double)want[i].pos.y;
+                const double a = fabs(dx) > fabs(dy) ? fabs(dx) : fabs(dy);
+                if (a > worst) worst = a;
+            }
+            rel = den > 0.0 ? sqrt(num / den) : sqrt(num);
+            bitwise = memcmp(got, want, (size_t)n * sizeof(Particle)) == 0;
+            fprintf(stderr, "nbody-bench: verify N=%u mode=%s steps=%u: ranks agree %s; vs single GPU: rel_l2_pos %.3e max_abs_pos %.3e bitwise %s\n",
+                    n, MODE_NAME[o->modes[mi]], o->verify_steps, agree ? "yes" : "NO", rel, worst, bitwise ? "yes" : "no");
+        }
+        bad = bad || !agree || !(rel <= 1e-5);
+    }
+    if (one) DestroyWorld(one);
+    DestroyWorld(w); /* collective-free: every rank tears its communicator down on its own */
+    return nb_rank_reduce(pg, (double)bad, 'x') > 0.0;
+}
+
+static int run_rank(const Options *o, NbRankPage *pg) {
+    const int rank = nb_rank_page_rank(pg), P = nb_rank_page_nranks(pg);
+    const int ndev = nb_hip_device_count();
+    if (ndev < 1 || (!o->transport_shm && ndev < P)) {
+        fprintf(stderr, "nbody-bench: rank %d: %d HIP device(s) visible, --gpus %d --transport rccl needs %d (one per rank)\n", rank, ndev, P, P);
+        nb_rank_page_fail(pg);
+        return 2;
+    }
+    nb_hip_set_device(o->transport_shm ? rank % ndev : rank);
+    srand(o->seed); /* the same stream on every rank: every rank draws the same universes */
+
+    if (rank == 0) {
+        printf("\t      N\t  ranks\t   mode\t     GPU us\t   steps/s\t  GPU int/s\t GPU %%peak\tkernel ms\tgather ms\n");
+        fflush(stdout);
+    }
+    int bad = 0;
+    for (uint32_t s = 0; s < o->n_sizes; s++) {
+        const uint32_t n = o->sizes[s];
+        Particle *ps = make_universe(o, n, s);
+        const double pairs = (double)n * (double)count_massive(ps, n);
+        if (o->verify_steps > 0) bad = verify_row(o, pg, ps, n) || bad;
+
+        World *w = make_sharded_world(o, pg, ps, n);
+        SimPipeline *sim = GetWorldPipeline(w);
+        nb_hip_configure(sim, "timing", 1);
+        for (int mi = 0; mi < o->n_modes; mi++) {
+            const int mode = o->modes[mi];
+            set_mode(w, mode);
+            /* the first call carries the upload; a captured chain is keyed on its length, so the graph row warms up
+             * with the timed length (capture + instantiate stay outside the timed call) */
+            UpdateWorld_GPU(w, o->dt, mode == MODE_GRAPH ? o->steps : (o->warmup > 0 ? o->warmup : 1));
+            double best = 0.0;
+            for (uint32_t r = 0; r < o->repeats; r++) {
+                nb_rank_barrier(pg, "before the timed call");
+                const double t0 = seconds_now();
+                UpdateWorld_GPU(w, o->dt, o->steps); /* blocking: the device is idle on return */
+                const double t1 = seconds_now();
+                nb_rank_barrier(pg, "after the timed call");
+                const double all = nb_rank_reduce(pg, t1 - t0, 'x'); /* max over ranks */
+                if (r == 0 || all < best) best = all;
+            }
+            double k_ms = 0.0, c_ms = 0.0;
+            const uint32_t covered = nb_hip_last_step_breakdown(sim, &k_ms, &c_ms);
+            k_ms = nb_rank_reduce(pg, covered ? k_ms / covered : 0.0, 'x');
+            c_ms = nb_rank_reduce(pg, covered ? c_ms / covered : 0.0, 'x');
+            if (s == 0 && mi == 0) {
+                /* what the communicator itself says: P real ranks, not P replicas */
+                int nr = 0, rk = 0, dev = 0, ver = 0;
+                double first_ms = 0.0;
+                char lib[256] = {0};
+                const int owns = nb_hip_comm_info(sim, &nr, &rk, &dev, &ver, &first_ms, lib, sizeof lib);
+                const double owners = nb_rank_reduce(pg, (double)owns, 's');
+                const double nr_min = nb_rank_reduce(pg, (double)nr, 'n'), nr_max = nb_rank_reduce(pg, (double)nr, 'x');
+                const double rk_sum = nb_rank_reduce(pg, (double)rk, 's');
+                if (rank == 0)
+                    fprintf(stderr, "nbody-bench: %d ranks, transport %s; ranks_with_communicator=%d ncclCommCount=%d..%d user_rank_sum=%d "
+                            "rccl=%d lib=%s first_gather_ms=%.3f; HIP runtime %d\n", P, o->transport_shm ? "shm" : "rccl", (int)owners,
+                            (int)nr_min, (int)nr_max, (int)rk_sum, ver, lib, first_ms, nb_hip_runtime_version());
+                if (!o->transport_shm && ((int)owners != P || (int)nr_min != P || (int)nr_max != P || (int)rk_sum != P * (P - 1) / 2)) bad = 1;
+            }
+            if (rank == 0) {
+                const double per = best / (double)o->steps;
+                printf("\t%7u\t%7d\t%7s\t%11.2f\t%10.2f\t%11.3e\t%9.1f\t%9.4f\t%9.4f\n", n, P, MODE_NAME[mode], per * 1e6, 1.0 / per,
+                       pairs / per, pairs / per * 14.0 / (157.3e12 * P) * 100.0, k_ms, c_ms);
+                fflush(stdout);
+            }
+        }
+        DestroyWorld(w);
+        free(ps);
+    }
+    nb_rank_barrier(pg, "end of the table");
+    return bad ? 1 : 0;
+}
+
+/* the page alone, no GPU: what `pytest -m "not gpu"` can run of the multi-process path */
+static int selftest_rank(const Options *o, NbRankPage *pg) {
+    const int rank = nb_rank_page_rank(pg), P = nb_rank_page_nranks(pg);
+    int bad = 0;
+    nb_rank_barrier(pg, "selftest start");
+    if (rank == o->selftest_die) _exit(7); /* the others are left waiting at the next barrier */
+    for (int round = 0; round < 3; round++) {
+        unsigned char id[NB_RANK_ID_BYTES];
+        memset(id, 0, sizeof id);
+        if (rank == 0)
+            for (int i = 0; i < NB_RANK_ID_BYTES; i++) id[i] = (unsigned char)(i * 7 + round);
+        nb_rank_share_id(pg, id);
+        for (int i = 0; i < NB_RANK_ID_BYTES; i++) bad = bad || id[i] != (unsigned char)(i * 7 + round);
+    }
+    bad = bad || nb_rank_reduce(pg, (double)(rank + 1), 'x') != (double)P;
+    bad = bad || nb_rank_reduce(pg, (double)(rank + 1), 'n') != 1.0;
+    bad = bad || nb_rank_reduce(pg, (double)(rank + 1), 's') != (double)(P * (P + 1) / 2);
+    bad = bad || !nb_rank_all_equal(pg, 42) || (P > 1 && nb_rank_all_equal(pg, (uint64_t)rank));
+    for (uint32_t per = 1; per <= 65536 && !bad; per *= 16) {
+        uint32_t *buf = (uint32_t *)malloc((size_t)per * 4 * (size_t)P);
+        for (int it = 0; it < 50; it++) {
+            memset(buf, 0xff, (size_t)per * 4 * (size_t)P);
+            for (uint32_t i = 0; i < per; i++) buf[(size_t)rank * per + i] = (uint32_t)rank * 1000003u + i * 31u + (uint32_t)it;
+            nb_rank_allgather(pg, buf, (uint64_t)per * 4, rank, P);
+            for (int q = 0; q < P; q++)
+                for (uint32_t i = 0; i < per; i++) bad = bad || buf[(size_t)q * per + i] != (uint32_t)q * 1000003u + i * 31u + (uint32_t)it;
+        }
+        free(buf);
+    }
+    bad = nb_rank_reduce(pg, (double)bad, 'x') > 0.0;
+    if (rank == 0)
+        printf("rank page selftest %s: %d ranks, %llu all-gathers per rank\n", bad ? "FAILED" : "ok", P, (unsigned long long)nb_rank_gather_calls(pg));
+    return bad;
+}
+
+/* fork the ranks (nothing has touched HIP yet), wait for all of them, end the stragglers once one has failed */
+static int run_ranks(const Options *o) {
+    const int P = o->gpus;
+    uint32_t max_n = 0;
+    for (uint32_t s = 0; s < o->n_sizes; s++) max_n = o->sizes[s] > max_n ? o->sizes[s] : max_n;
+    /* largest exchange: the particle slices of a collective read-back, P x (Mc + Zc) records of 32 bytes with
+     * Mc + Zc <= 2 x (N / P + 65) (shard_plan.hip rounds both chunks up to 64) */
+    const size_t exchange = o->selftest_ranks ? (size_t)P * 65536 * 4 : o->transport_shm ? 64 * ((size_t)max_n + 65 * (size_t)P) + 4096 : 0;
+    NbRankPage *pg = nb_rank_page_create(P, exchange, o->wait_timeout_s);
+    if (!pg) {
+        perror("nbody-bench: cannot map the shared rank page");
+        return 2;
+    }
+    /* multi-process GPU work on this pool needs dmabuf IPC (RCCL's P2P handles) */
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+    if (o->force_sharded) setenv("NB_HIP_FORCE_SHARDED", "1", 1);
+    fflush(stdout);
+    fflush(stderr);
+    pid_t pids[NB_RANKS_MAX];
+    for (int r = 0; r < P; r++) {
+        pids[r] = fork();
+        if (pids[r] < 0) {
+            perror("nbody-bench: fork");
+            nb_rank_page_fail(pg);
+            for (int q = 0; q < r; q++) kill(pids[q], SIGKILL);
+            return 2;
+        }
+        if (pids[r] == 0) {
+            nb_rank_page_attach(pg, r);
+            const int rc = o->selftest_ranks ? selftest_rank(o, pg) : run_rank(o, pg);
+            fflush(stdout);
+            fflush(stderr);
+            _exit(rc);
+        }
+    }
+    int alive = P, worst = 0;
+    double failed_at = 0.0;
+    while (alive > 0) {
+        int st = 0;
+        const pid_t pid = waitpid(-1, &st, WNOHANG);
+        if (pid > 0) {
+            int r = 0;
+            while (r < P && pids[r] != pid) r++;
+            if (r == P) continue;
+            pids[r] = 0;
+            alive--;
+            const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+            if (rc != 0) {
+                fprintf(stderr, "nbody-bench: rank %d (pid %ld) ended with status %d\n", r, (long)pid, rc);
+                if (worst == 0) worst = rc;
+                nb_rank_page_fail(pg); /* every rank waiting at the page leaves on its own (exit 4) */
+                if (failed_at == 0.0) failed_at = seconds_now();
+            }
+            continue;
+        }
+        struct timespec ts = {0, 20 * 1000 * 1000};
+        nanosleep(&ts, NULL);
+        if (failed_at > 0.0 && seconds_now() - failed_at > 15.0) {
+            /* a rank stuck inside a collective whose peer is gone: end exactly the children this process started */
+            for (int r = 0; r < P; r++)
+                if (pids[r] > 0) {
+                    fprintf(stderr, "nbody-bench: ending rank %d (pid %ld) 15 s after another rank failed\n", r, (long)pids[r]);
+                    kill(pids[r], SIGKILL);
+                }
+            failed_at = seconds_now() + 1e9; /* once */
+        }
+    }
+    nb_rank_page_destroy(pg);
+    return worst;
+}
+
+static int parse_modes(Options *o, const char *list) {
+    o->n_modes = 0;
+    char tmp[128];
+    snprintf(tmp, sizeof tmp, "%s", list);
+    for (char *tok = strtok(tmp, ","); tok && o->n_modes < 8; tok = strtok(NULL, ",")) {
+        int m = -1;
+        for (int i = 0; i < MODE_COUNT; i++)
+            if (!strcmp(tok, MODE_NAME[i])) m = i;
+        if (m < 0) return -1;
+        o->modes[o->n_modes++] = m;
+    }
+    return o->n_modes > 0 ? 0 : -1;
+}
+
+int main(int argc, char **argv) {
+    Options o;
+    memset(&o, 0, sizeof o);
+    o.use_cpu = o.use_gpu = true;
+    o.steps = 100, o.warmup = 10, o.galaxies = 2, o.repeats = 1, o.verify_steps = 3;
+    o.seed = 11037;
+    o.dt = 1.f;
+    o.gpus = 1;
+    o.wait_timeout_s = 180.0;
+    o.selftest_die = -1;
+    const char *modes = NULL;
+
+    for (int a = 1; a < argc; a++) {
+        const char *arg = argv[a];
+        const char *val = a + 1 < argc ? argv[a + 1] : NULL;
+        if (!strcmp(arg, "--cpu")) {
+            o.use_gpu = false;
+        } else if (!strcmp(arg, "--gpu")) {
+            o.use_cpu = false;
+        } else if (!strcmp(arg, "--n") && val && o.n_sizes < 64) {
+            o.sizes[o.n_sizes++] = (uint32_t)strtoul(val, NULL, 0), a++;
+        } else if (!strcmp(arg, "--steps") && val) {
+            o.steps = (uint32_t)strtoul(val, NULL, 0), a++;
+        } else if (!strcmp(arg, "--warmup") && val) {
+            o.warmup = (uint32_t)strtoul(val, NULL, 0), a++;
+        } else if (!strcmp(arg, "--dt") && val) {
+            o.dt = strtof(val, NULL), a++;
+        } else if (!strcmp(arg, "--galaxies") && val) {
+            o.galaxies = (uint32_t)strtoul(val, NULL, 0), a++;
+        } else if (!strcmp(arg, "--seed") && val) {
+            o.seed = (unsigned)strtoul(val, NULL, 0), a++;
+        } else if (!strcmp(arg, "--repeats") && val) {
+            o.repeats = (uint32_t)strtoul(val, NULL, 0), a++;
+        } else if (!strcmp(arg, "--floor-rate") && val) {
+            o.floor_rate = strtod(val, NULL), a++;
+        } else if (!strcmp(arg, "--own-rng")) {
+            o.own_rng = true;
+        } else if (!strcmp(arg, "--gpus") && val) {
+            o.gpus = atoi(val), a++;
+        } else if (!strcmp(arg, "--transport") && val && (!strcmp(val, "rccl") || !strcmp(val, "shm"))) {
+            o.transport_shm = !strcmp(val, "shm"), a++;
+        } else if (!strcmp(arg, "--modes") && val) {
+            modes = val, a++;
+        } else if (!strcmp(arg, "--verify") && val) {
+            o.verify_steps = (uint32_t)strtoul(val, NULL, 0), o.verify_given = true, a++;
+        } else if (!strcmp(arg, "--wait-timeout") && val) {
+            o.wait_timeout_s = strtod(val, NULL), a++;
+        } else if (!strcmp(arg, "--force-sharded")) {
+            o.force_sharded = true;
+        } else if (!strcmp(arg, "--selftest-ranks")) {
+            o.selftest_ranks = true;
+        } else if (!strcmp(arg, "--selftest-die") && val) {
+            o.selftest_die = atoi(val), a++;
+        } else {
+            fprintf(stderr,
+                    "usage: %s [--cpu|--gpu] [--n N]... [--steps K] [--warmup W] [--dt DT] [--galaxies G] [--seed S]"
+                    " [--own-rng] [--repeats R] [--floor-rate INT_PER_S]\n"
+                    "       [--gpus P [--transport rccl|shm] [--modes plain,overlap,graph] [--verify K] [--force-sharded]"
+                    " [--wait-timeout S] [--selftest-ranks]]\n",
+                    argv[0]);
+            return 2;
+        }
+    }
+    if (o.n_sizes == 0) {
+        o.n_sizes = sizeof REFERENCE_SIZES / sizeof REFERENCE_SIZES[0];
+        memcpy(o.sizes, REFERENCE_SIZES, sizeof REFERENCE_SIZES);
+    }
+    if (o.steps == 0) o.steps = 1;
+    if (o.repeats == 0) o.repeats = 1;
+    if (o.gpus < 1 || o.gpus > NB_RANKS_MAX) {
+        fprintf(stderr, "nbody-bench: --gpus must be 1..%d\n", NB_RANKS_MAX);
+        return 2;
+    }
+    if (parse_modes(&o, modes ? modes : (o.transport_shm ? "plain,overlap" : "plain,overlap,graph")) != 0) {
+        fprintf(stderr, "nbody-bench: --modes takes a comma list of plain, overlap, graph\n");
+        return 2;
+    }
+    if (o.transport_shm)
+        for (int i = 0; i < o.n_modes; i++)
+            if (o.modes[i] == MODE_GRAPH) {
+                fprintf(stderr, "nbody-bench: mode graph needs --transport rccl (a host callback cannot run inside a captured graph)\n");
+                return 2;
+            }
+    if (o.gpus > 1 || o.force_sharded || o.selftest_ranks) return run_ranks(&o);
+    return run_single(&o);
 }

@@ -57,7 +57,8 @@ static uint32_t partition_by_mass(Particle *p, uint32_t count) {
 }
 
 /* rank < 0: an ordinary single-GPU World; otherwise the sharded pipeline of include/nbody_hip.h. */
-static World *create_world(const Particle *ps, uint32_t size, int rank, int nranks, const void *unique_id128) {
+static World *create_world(const Particle *ps, uint32_t size, int rank, int nranks, const void *unique_id128,
+                           NbAllGatherFn allgather, void *ctx) {
     World *w = NB_NEW(1, World);
     NB_CHECK(w != NULL, "Failed to alloc World");
     w->particles = NB_NEW(size ? size : 1, Particle);
@@ -67,7 +68,9 @@ static World *create_world(const Particle *ps, uint32_t size, int rank, int nran
     w->count = size;
     w->massive = partition_by_mass(w->particles, size);
     const WorldData data = {.total_len = size, .mass_len = w->massive, .dt = 0.0f};
-    w->gpu = rank < 0 ? CreateSimPipeline(data) : CreateSimPipelineSharded(data, rank, nranks, unique_id128);
+    w->gpu = rank < 0     ? CreateSimPipeline(data)
+             : allgather ? CreateSimPipelineShardedWith(data, rank, nranks, allgather, ctx)
+                         : CreateSimPipelineSharded(data, rank, nranks, unique_id128);
     /* this array is what every later Set/GetSimulationData moves: let the pipeline page-lock it when (if) it
      * first touches the GPU.  DestroyWorld destroys the pipeline before freeing the array. */
     nb_hip_note_host_array(w->gpu, w->particles, (uint64_t)size * sizeof(Particle));
@@ -77,7 +80,7 @@ static World *create_world(const Particle *ps, uint32_t size, int rank, int nran
     return w;
 }
 
-World *CreateWorld(const Particle *ps, uint32_t size) { return create_world(ps, size, -1, 1, NULL); }
+World *CreateWorld(const Particle *ps, uint32_t size) { return create_world(ps, size, -1, 1, NULL, NULL, NULL); }
 
 /*
  * Extension: one World per process and GPU.  The partition is deterministic, so every rank derives the same
@@ -86,8 +89,17 @@ World *CreateWorld(const Particle *ps, uint32_t size) { return create_world(ps, 
  */
 World *CreateWorldSharded(const Particle *ps, uint32_t size, int rank, int nranks, const void *unique_id128) {
     NB_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "rank %d of %d", rank, nranks);
-    return create_world(ps, size, rank, nranks, unique_id128);
+    return create_world(ps, size, rank, nranks, unique_id128, NULL, NULL);
 }
+
+/* Extension: the same over a caller-supplied host all-gather (several ranks on ONE GPU, machines without RCCL). */
+World *CreateWorldShardedWith(const Particle *ps, uint32_t size, int rank, int nranks, NbAllGatherFn allgather, void *ctx) {
+    NB_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "rank %d of %d", rank, nranks);
+    NB_CHECK(allgather != NULL, "NULL all-gather callback");
+    return create_world(ps, size, rank, nranks, NULL, allgather, ctx);
+}
+
+SimPipeline *GetWorldPipeline(World *w) { return w ? w->gpu : NULL; }
 
 void DestroyWorld(World *w) {
     if (w == NULL) return;

@@ -42,7 +42,9 @@ def test_nbody_library_exports_public_surface():
     assert set(names) == {"CreateWorld", "DestroyWorld", "GetWorldParticles", "UpdateWorld_CPU",
                           "UpdateWorld_GPU", "MakeGalaxies",   # reference nbody.h:61-73, galaxy.h:64
                           "MakeGalaxiesSeeded",                # extension: libc-independent draws
-                          "CreateWorldSharded"}                # extension: one World per process and GPU
+                          "CreateWorldSharded",                # extension: one World per process and GPU
+                          "CreateWorldShardedWith",            # ... over a caller-supplied host all-gather
+                          "GetWorldPipeline"}                  # extension: the pipeline behind a World (knobs, timers)
     have = exported(nb.NBODY_SO)
     assert not [n for n in names if n not in have]
 
@@ -233,3 +235,36 @@ def test_small_launch_model_against_the_committed_shape_scan():
         assert regrets[-1] <= 0.06, f"N={int(n)}: pick {p} measured {hit[0, 7]} us, scan's best {sub[:, 7].min()} us"
     assert len(regrets) >= 12
     assert np.mean(regrets) <= 0.025, regrets
+
+
+# ---- nbody-bench --gpus P: the shared rank page (rank_page.c), no GPU involved -------------------------------------------
+
+BENCH_EXE = os.path.join(nb.LIB_DIR, "nbody-bench")
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 8])
+def test_rank_page_selftest_with_real_processes(P):
+    """P forked processes meet at barriers, pass three 128-byte ids from rank 0, reduce max / min / sum, compare words and
+    run 250 shared-memory all-gathers of 4 B .. 256 KiB per rank, each checked element by element."""
+    nb.nbody_lib()   # builds the product (and nbody-bench) when missing
+    r = subprocess.run([BENCH_EXE, "--gpus", str(P), "--selftest-ranks"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert r.stdout.strip() == f"rank page selftest ok: {P} ranks, 250 all-gathers per rank"
+
+
+def test_rank_page_a_dying_rank_ends_the_run_quickly():
+    """One rank leaves with status 7 while the others wait at a barrier: they notice the failed page, leave with 4, the
+    parent reaps all of them and reports the first failure -- well inside the 180 s wait timeout."""
+    import time
+    nb.nbody_lib()
+    t0 = time.time()
+    r = subprocess.run([BENCH_EXE, "--gpus", "4", "--selftest-ranks", "--selftest-die", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 7 and time.time() - t0 < 20
+    assert "rank 2" in r.stderr and "ended with status 7" in r.stderr and r.stderr.count("leaving (exit 4)") == 3
+    assert "selftest ok" not in r.stdout
+
+
+def test_nbody_bench_rejects_a_captured_graph_over_the_host_transport():
+    nb.nbody_lib()
+    r = subprocess.run([BENCH_EXE, "--gpus", "2", "--transport", "shm", "--modes", "plain,graph"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "graph needs --transport rccl" in r.stderr

@@ -1286,6 +1286,83 @@ def test_nbody_bench_gpu_column():
     assert all(float(x[2]) > 1e9 for x in rows[1:])
 
 
+def test_nbody_bench_verify_column_compares_gpu_with_the_cpu_path():
+    """nbody-bench --verify K: K steps of UpdateWorld_GPU against K steps of UpdateWorld_CPU (bit-exact with the reference
+    AVX build, tests/test_world_cpu.py) per row, relative to what the steps moved; the harness itself fails above 1e-4."""
+    import re
+    exe = os.path.join(nb.LIB_DIR, "nbody-bench")
+    r = subprocess.run([exe, "--n", "1200", "--n", "10000", "--steps", "5", "--warmup", "1", "--dt", "0.01", "--verify", "10"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    devs = [float(x) for x in re.findall(r"GPU vs CPU rel_displacement ([0-9.e+-]+)", r.stderr)]
+    assert len(devs) == 2 and all(d <= 1e-5 for d in devs), r.stderr      # observed ~1e-6: summation order only
+    assert r.stderr.count("mass/radius equal yes") == 2
+
+
+def _bench_ranks(args, env=None, timeout=600):
+    exe = os.path.join(nb.LIB_DIR, "nbody-bench")
+    e = dict(os.environ, OMP_NUM_THREADS="2")
+    e.update(env or {})
+    return subprocess.run([exe] + args, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("P,n", [(2, 4000), (3, 1200), (3, 20000)])
+def test_nbody_bench_c_ranks_on_one_gpu_bitwise(P, n):
+    """nbody-bench --gpus P --transport shm: P REAL processes forked by the C harness before anything touched HIP, each
+    with its own HIP context on this one GPU, one World stepped through CreateWorldShardedWith over the shared page --
+    no Python, no torch, /opt/rocm's HIP runtime.  With one wave per workgroup (NB_HIP_W=1, NB_HIP_K=1) the summation
+    order does not depend on the launch geometry: the in-stream (plain) step must equal the single-GPU World bit for bit."""
+    import re
+    r = _bench_ranks(["--gpus", str(P), "--transport", "shm", "--n", str(n), "--steps", "6", "--warmup", "2", "--dt", "0.01",
+                      "--modes", "plain", "--verify", "4"], env={"NB_HIP_W": "1", "NB_HIP_K": "1"})
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    v = re.findall(r"verify N=(\d+) mode=(\w+) steps=4: ranks agree (\w+); vs single GPU: rel_l2_pos ([0-9.e+-]+) max_abs_pos ([0-9.e+-]+) bitwise (\w+)", r.stderr)
+    assert v == [(str(n), "plain", "yes", v[0][3], v[0][4], "yes")] and float(v[0][3]) == 0.0, r.stderr
+    rows = [l.split() for l in r.stdout.strip().splitlines()]
+    assert rows[0][:4] == ["N", "ranks", "mode", "GPU"] and rows[1][:3] == [str(n), str(P), "plain"]
+    assert float(rows[1][3]) > 0 and float(rows[1][-2]) > 0 and float(rows[1][-1]) > 0     # us/step, kernel ms, gather ms
+    assert f"{P} ranks, transport shm; ranks_with_communicator=0" in r.stderr
+
+
+def test_nbody_bench_c_ranks_default_shapes_and_overlap():
+    """The same with the library's own launch shapes, both step modes, two sizes in one run (the second World gets a
+    fresh exchange): every rank holds the same bytes and they stay within 1e-5 relative L2 of the single-GPU positions
+    (the harness' own bound; observed ~1e-8)."""
+    import re
+    r = _bench_ranks(["--gpus", "2", "--transport", "shm", "--n", "4096", "--n", "65536", "--steps", "5", "--warmup", "1", "--dt", "0.01"])
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    v = re.findall(r"verify N=(\d+) mode=(\w+) steps=3: ranks agree (\w+); vs single GPU: rel_l2_pos ([0-9.e+-]+)", r.stderr)
+    assert [(a, b, c) for a, b, c, _ in v] == [("4096", "plain", "yes"), ("4096", "overlap", "yes"), ("65536", "plain", "yes"),
+                                               ("65536", "overlap", "yes")], r.stderr
+    assert all(float(x[3]) <= 1e-6 for x in v)
+    rows = [l.split() for l in r.stdout.strip().splitlines()][1:]
+    assert [(x[0], x[2]) for x in rows] == [("4096", "plain"), ("4096", "overlap"), ("65536", "plain"), ("65536", "overlap")]
+    assert all(float(x[5]) > 1e9 for x in rows)
+
+
+def test_nbody_bench_c_one_forced_rccl_rank():
+    """nbody-bench --gpus 1 --force-sharded: the RCCL path (ncclCommInitRank, in-place ncclAllGather per step, the chain
+    captured as a hipGraph, the overlapped step) with ONE rank, forked by the C harness -- the HIP runtime and librccl
+    this binds are /opt/rocm's (no torch in the process), which is what a real --gpus 8 run binds too."""
+    import re
+    r = _bench_ranks(["--gpus", "1", "--force-sharded", "--n", "20000", "--steps", "8", "--warmup", "2", "--dt", "0.01"])
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "1 ranks, transport rccl; ranks_with_communicator=1 ncclCommCount=1..1" in r.stderr
+    lib = re.search(r"lib=(\S+)", r.stderr).group(1)
+    assert "librccl" in lib and "torch" not in lib, lib
+    v = re.findall(r"mode=(\w+) steps=3: ranks agree yes; vs single GPU: rel_l2_pos ([0-9.e+-]+)", r.stderr)
+    assert [m for m, _ in v] == ["plain", "overlap", "graph"] and all(float(x) <= 1e-6 for _, x in v), r.stderr
+    rows = [l.split() for l in r.stdout.strip().splitlines() if l.split() and l.split()[0] == "20000"]
+    assert [x[2] for x in rows] == ["plain", "overlap", "graph"] and all(float(x[5]) > 1e9 for x in rows)
+
+
+def test_nbody_bench_c_ranks_refuses_rccl_without_enough_devices():
+    if nb.device_count() >= 2:
+        pytest.skip("more than one GPU here")
+    r = _bench_ranks(["--gpus", "2", "--n", "1200", "--steps", "2"], timeout=120)
+    assert r.returncode != 0 and "needs 2 (one per rank)" in r.stderr
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(ob.ORACLE_DIR, "_ref", "nbody-bench-ref")),
                     reason="oracle/_ref/nbody-bench-ref not built")
 def test_reference_bench_c_runs_unchanged_on_our_library():
