@@ -137,8 +137,16 @@ typedef struct Options {
     int selftest_die; /* --selftest-die R: that rank leaves with status 7 mid-run (the parent's reaping is what is tested) */
 } Options;
 
-static Particle *make_universe(const Options *o, uint32_t n, uint32_t row) {
-    return o->own_rng ? MakeGalaxiesSeeded(n, o->galaxies, o->seed + row) : MakeGalaxies(n, o->galaxies);
+/* Every universe of the table, drawn up front from ONE srand(seed) stream in table order, like the reference
+ * (bench.c:42,53) -- and BEFORE this process first touches the GPU: libc's rand() is process-global and the HIP runtime
+ * draws from it too (observed: two ranks whose GPU call sequences differed drew different second universes), so
+ * interleaving MakeGalaxies with GPU work would make the rows depend on what ran before them. */
+static Particle **draw_universes(const Options *o) {
+    Particle **u = (Particle **)malloc(sizeof(Particle *) * (o->n_sizes ? o->n_sizes : 1));
+    srand(o->seed);
+    for (uint32_t s = 0; s < o->n_sizes; s++)
+        u[s] = o->own_rng ? MakeGalaxiesSeeded(o->sizes[s], o->galaxies, o->seed + s) : MakeGalaxies(o->sizes[s], o->galaxies);
+    return u;
 }
 
 /* ---- one process, one GPU: the reference's table ------------------------------------------------------------------ */
@@ -173,13 +181,12 @@ static int verify_backends(const Options *o, const Particle *ps, uint32_t n) {
 
 static int run_single(const Options *o) {
     int bad = 0;
+    Particle **universe = draw_universes(o);
     double floor_rate = o->floor_rate;
     if (o->use_gpu && floor_rate <= 0.0) {
         floor_rate = measure_large_n_rate();
         fprintf(stderr, "nbody-bench: floor rate %.3e interactions/s (measured at N = %u on this box)\n", floor_rate, CALIBRATION_N);
     }
-
-    srand(o->seed); /* one seed for the whole table, as the reference */
 
     printf("\t      N");
     if (o->use_cpu) printf("\t    CPU");
@@ -190,7 +197,7 @@ static int run_single(const Options *o) {
 
     for (uint32_t s = 0; s < o->n_sizes; s++) {
         const uint32_t n = o->sizes[s];
-        Particle *ps = make_universe(o, n, s);
+        Particle *ps = universe[s];
         const double pairs = (double)n * (double)count_massive(ps, n);
 
         double cpu_s = 0, gpu_s = 0;
@@ -229,6 +236,7 @@ static int run_single(const Options *o) {
         if (o->use_cpu && o->use_gpu && o->verify_given && o->verify_steps > 0) bad = verify_backends(o, ps, n) || bad;
         free(ps);
     }
+    free(universe);
     return bad;
 }
 
@@ -297,6 +305,7 @@ static int verify_row(const Options *o, NbRankPage *pg, const Particle *ps, uint
 
 static int run_rank(const Options *o, NbRankPage *pg) {
     const int rank = nb_rank_page_rank(pg), P = nb_rank_page_nranks(pg);
+    Particle **universe = draw_universes(o); /* the same stream on every rank, before any GPU call: identical universes */
     const int ndev = nb_hip_device_count();
     if (ndev < 1 || (!o->transport_shm && ndev < P)) {
         fprintf(stderr, "nbody-bench: rank %d: %d HIP device(s) visible, --gpus %d --transport rccl needs %d (one per rank)\n", rank, ndev, P, P);
@@ -304,7 +313,6 @@ static int run_rank(const Options *o, NbRankPage *pg) {
         return 2;
     }
     nb_hip_set_device(o->transport_shm ? rank % ndev : rank);
-    srand(o->seed); /* the same stream on every rank: every rank draws the same universes */
 
     if (rank == 0) {
         printf("\t      N\t  ranks\t   mode\t     GPU us\t   steps/s\t  GPU int/s\t GPU %%peak\tkernel ms\tgather ms\n");
@@ -313,8 +321,13 @@ static int run_rank(const Options *o, NbRankPage *pg) {
     int bad = 0;
     for (uint32_t s = 0; s < o->n_sizes; s++) {
         const uint32_t n = o->sizes[s];
-        Particle *ps = make_universe(o, n, s);
+        Particle *ps = universe[s];
         const double pairs = (double)n * (double)count_massive(ps, n);
+        /* belt and braces: the ranks must be about to step the same bytes */
+        if (!nb_rank_all_equal(pg, fnv1a(ps, (size_t)n * sizeof(Particle)))) {
+            if (rank == 0) fprintf(stderr, "nbody-bench: the ranks drew different universes at N=%u\n", n);
+            bad = 1;
+        }
         if (o->verify_steps > 0) bad = verify_row(o, pg, ps, n) || bad;
 
         World *w = make_sharded_world(o, pg, ps, n);
@@ -365,6 +378,7 @@ static int run_rank(const Options *o, NbRankPage *pg) {
         DestroyWorld(w);
         free(ps);
     }
+    free(universe);
     nb_rank_barrier(pg, "end of the table");
     return bad ? 1 : 0;
 }

@@ -78,6 +78,8 @@ void release_device(SimPipeline *s) {
     s->on_device = false;
 }
 
+void set_simulation_data(SimPipeline *s, const Particle *ps);
+
 // First touch of the GPU for this pipeline: stream, events, HBM buffers.
 void materialize(SimPipeline *s) {
     use_device();
@@ -296,7 +298,22 @@ void DestroySimPipeline(SimPipeline *sim) {
 void SetSimulationData(SimPipeline *s, const Particle *ps) {
     NB_ASSERT(s != nullptr, "NULL pipeline");
     NB_ASSERT(ps != nullptr || s->data.total_len == 0, "NULL particle array");
-    materialize(s);
+    if (!s->on_device) {
+        // first touch: streams, HBM, page-locking, code objects -- none of it may move the caller's rand() stream
+        RandGuard keep_callers_rand_stream;
+        materialize(s);
+        set_simulation_data(s, ps);
+        return;
+    }
+    use_device();
+    set_simulation_data(s, ps);
+}
+
+}  // extern "C"
+
+namespace {
+
+void set_simulation_data(SimPipeline *s, const Particle *ps) {
     const uint32_t N = s->data.total_len, M = s->data.mass_len;
     if (N == 0) return;
     hipStream_t st = s->stream;
@@ -328,6 +345,10 @@ void SetSimulationData(SimPipeline *s, const Particle *ps) {
     // small worlds in auto mode: have the canonical chain ready before the first step call (see wants_canonical)
     if (wants_canonical(s)) (void)find_or_build_graph(s, CANON_STEPS, 0.0f, resolve_shape(s));
 }
+
+}  // namespace
+
+extern "C" {
 
 void GetSimulationData(const SimPipeline *cs, Particle *ps) {
     SimPipeline *s = const_cast<SimPipeline *>(cs);

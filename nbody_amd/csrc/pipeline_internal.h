@@ -69,6 +69,24 @@ void use_device();     // ensure_device + hipSetDevice on the calling thread (HI
 void *dev_alloc_bytes(size_t bytes);
 void dev_free(void *p);
 
+// libc's rand() stream belongs to the caller: the reference harness seeds it ONCE and draws every universe of its table
+// from it (src/bench.c:42,53), between GPU calls.  The HIP runtime's first stream / allocation / code-object set-up
+// draws from (or reseeds) that same process-global state -- measured: tools/rand_probe.py, profiles/r04_rand_probe.txt --
+// so the first device set-up of a pipeline and RCCL's bootstrap run with a private state swapped in.
+class RandGuard {
+  public:
+    RandGuard() { old_ = initstate(1u, buf_, sizeof buf_); }
+    ~RandGuard() {
+        if (old_) setstate(old_);
+    }
+    RandGuard(const RandGuard &) = delete;
+    RandGuard &operator=(const RandGuard &) = delete;
+
+  private:
+    char buf_[128];
+    char *old_;
+};
+
 template <typename T>
 T *dev_alloc(size_t count) {
     return static_cast<T *>(dev_alloc_bytes((count ? count : 1) * sizeof(T)));

@@ -114,6 +114,7 @@ void Watchdog::run() {
 
 void comm_create(SimPipeline *s, const void *unique_id128) {
     const int rank = s->rank, nranks = s->nranks;
+    RandGuard keep_callers_rand_stream;  // RCCL's bootstrap and HIP's first set-up draw from libc's rand()
     use_device();  // the communicator binds to the current device
     ncclUniqueId id;
     memcpy(&id, unique_id128, NB_HIP_UNIQUE_ID_BYTES);
@@ -176,6 +177,7 @@ extern "C" {
 
 void nb_hip_comm_unique_id(void *out128) {
     NB_ASSERT(out128 != nullptr, "NULL id buffer");
+    nbi::RandGuard keep_callers_rand_stream;
     ncclUniqueId id;
     ASSERT_NCCL(rccl().GetUniqueId(&id), "ncclGetUniqueId");
     memcpy(out128, &id, NB_HIP_UNIQUE_ID_BYTES);

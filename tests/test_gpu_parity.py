@@ -1299,6 +1299,22 @@ def test_nbody_bench_verify_column_compares_gpu_with_the_cpu_path():
     assert r.stderr.count("mass/radius equal yes") == 2
 
 
+def test_gpu_work_leaves_the_callers_rand_stream_alone():
+    """The reference harness seeds libc's rand() once and draws every universe of its table from it between GPU calls
+    (src/bench.c:42,53); the HIP runtime's first set-up draws from the same process-global state.  The library swaps a
+    private state in around it (RandGuard): in a fresh process, the values after srand(1) are the same with and
+    without a World's whole GPU life in between."""
+    code = ("import ctypes as C, numpy as np, nbody_amd as nb\n"
+            "libc = C.CDLL(None); libc.srand(1); plain = [libc.rand() for _ in range(5)]\n"
+            "ic = nb.make_galaxies(2000, 2, own_rng=True, seed=3)\n"
+            "libc.srand(1)\n"
+            "w = nb.World(ic); w.update_gpu(0.01, 3); w.particles(); w.update_gpu(0.01, 40); w.close()\n"
+            "got = [libc.rand() for _ in range(5)]\n"
+            "print('SAME' if got == plain else 'DISTURBED', plain, got)\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=nb.ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("SAME"), (r.stdout, r.stderr[-2000:])
+
+
 def _bench_ranks(args, env=None, timeout=600):
     exe = os.path.join(nb.LIB_DIR, "nbody-bench")
     e = dict(os.environ, OMP_NUM_THREADS="2")
