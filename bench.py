@@ -19,18 +19,23 @@ steps), C3 (N = 262 144, a cached hipGraph chain at dt, then the same chain at d
 nbody-bench --cpu, no GPU).
 
 N > 1: strong scaling -- the same 2^20 particles, N/P receivers per GPU, all-gather of source positions
-per step over RCCL inside the library; torch.distributed (gloo) only carries the rendezvous, the barrier
-and the reductions of the timings.  The JSON dict is COMPLETE after the headline leg and the self-check (what the
+per step over RCCL inside the library.  The rendezvous, the barriers and the reductions of the timings go over a
+stdlib Unix-socket hub between the ranks (nbody_amd/ranklink.py): torch is NOT imported, so the HIP runtime and the
+librccl the data path binds are /opt/rocm's -- the stack every single-GPU test runs on -- and not the ones bundled with
+the torch wheel.  `--rendezvous gloo` keeps the round-3 route (torch.distributed gloo; torch's runtime loads first).  The JSON dict is COMPLETE after the headline leg and the self-check (what the
 RCCL communicator itself reports, per-step kernel / all-gather times, all ranks agree and match a single-GPU run);
 every later leg (`extra_configs`: overlapped step, the chain captured as a hipGraph, BASELINE.json's config 5 at
 N = 2^22 plain and overlapped) runs under a host-side deadline: if one stalls, rank 0 writes the line with what is
 in hand plus "extras_aborted": "<leg>" and every rank leaves with exit code 4 -- a fresh exit, never a re-exec.
 
-Runtime note: under torch.distributed.run torch is imported before libnbody_hip.so is loaded, so the HIP runtime
-and librccl that the data path binds are the ones bundled with the torch wheel (ROCm 7.0 build); a plain
-`python bench.py` binds /opt/rocm's.  `runtime` in the JSON line says which.
+`runtime` in the JSON line says which HIP runtime and librccl the run bound.
 
-The oracle (oracle/) is used here ONLY for the cpu_baseline leg.
+Every single-GPU leg carries a parity stamp: OUTSIDE the timed region the state the timed steps left is read back, one
+more step runs, and that step is checked -- sampled accelerations against the oracle's float64 sum (the stated
+tolerance) and against the reference AVX order, the integrator identity bit for bit over all N particles.
+
+The oracle (oracle/) is used here ONLY as the timed cpu_baseline and as the checker behind the parity stamps; nothing
+that is timed as "the GPU path" goes through it.
 """
 import argparse
 import ctypes as C
@@ -191,6 +196,50 @@ def _time_reference_packedupdate(so, part, mass_len, recv, cores):
     return sec
 
 
+# ---- parity stamp ----------------------------------------------------------------------------------------------------
+
+def parity_stamp(sim, mass_len, dt=DT, samples=256):
+    """What the line says about the correctness of what it timed.  Reads the state S the timed steps left, runs ONE more
+    step on the same pipeline (same launch shape, same route) and checks that step against the oracle (the checker,
+    tests/oracle_binding.py -- never the thing measured):
+      * acc of `samples` receivers (half massive, half anywhere, plus the first / last of each range) against the
+        float64 sum of the same state: worst |acc - acc_f64| / (1e-4 |acc_f64| + 1e-6 sum_j |contribution_j|), the stated
+        one-step tolerance (<= 1 passes);
+      * the same receivers against the reference AVX order's fp32 result, as a fraction of sum_j |contribution_j|;
+      * vel == vel0 + acc * dt and pos == pos0 + vel * dt in fp32 with the reference's roundings (sim_cpu.c:191-193) and
+        mass / radius untouched, over ALL particles, bit for bit."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+
+    before = sim.get_data()
+    sim.update(1, dt)
+    after = sim.get_data()
+    n = before.shape[0]
+    rng = np.random.default_rng(20260401)
+    picks = [rng.integers(0, n, samples // 2), [0, n - 1]]
+    if mass_len:
+        picks += [rng.integers(0, mass_len, samples // 2), [mass_len - 1, min(mass_len, n - 1)]]
+    idx = np.unique(np.concatenate(picks)).astype(np.uint32)
+    acc64, mag = ob.acc_f64_subset(before, mass_len, idx)
+    got = after[idx, 4:6].astype(np.float64)
+    bound = 1e-4 * np.abs(acc64) + 1e-6 * mag
+    safe = np.where(bound > 0, bound, 1.0)
+    ratio = np.where(bound > 0, np.abs(got - acc64) / safe, np.where(got == acc64, 0.0, np.inf))
+    avx = ob.acc_avx_subset(before, mass_len, idx).astype(np.float64)
+    scale = np.where(mag > 0, mag, 1.0)
+    avx_ratio = np.where(bound > 0, np.abs(avx - acc64) / safe, 0.0)
+    v = before[:, 2:4] + after[:, 4:6] * np.float32(dt)
+    pos = before[:, 0:2] + v * np.float32(dt)
+    return {"checked": int(idx.size), "worst_ratio": float(ratio.max()),
+            "gpu_vs_avx_max": float((np.abs(got - avx) / scale).max()),
+            "avx_vs_f64_worst_ratio": float(avx_ratio.max()),
+            "integrator_bit_exact": bool(np.array_equal(after[:, 2:4], v) and np.array_equal(after[:, 0:2], pos)),
+            "static_fields_equal": bool(np.array_equal(after[:, 6:8], before[:, 6:8])),
+            "note": "one extra step after the timed call, outside the timed region; worst_ratio = |acc_gpu - acc_f64| / "
+                    "(1e-4 |acc_f64| + 1e-6 sum|contrib|) over the sampled receivers (<= 1 = within the stated tolerance); "
+                    "gpu_vs_avx_max = |acc_gpu - acc_avx| / sum|contrib|; integrator identity over all particles"}
+
+
 # ---- roofline.traffic: tied to the committed PMC profile ----------------------------------------------------------------
 
 def kernel_sources_sha():
@@ -348,9 +397,14 @@ def main():
                     help="size of the second sharded workload under extra_configs (default 2^22 = BASELINE.json config 5)")
     ap.add_argument("--transport", choices=("rccl", "host"), default="rccl",
                     help="N > 1: rccl = in-stream ncclAllGather (the product path); host = the library's caller-supplied "
-                         "transport over torch.distributed gloo (host-staged, slow): lets several ranks share ONE GPU to "
+                         "transport over the rendezvous link (host-staged, slow): lets several ranks share ONE GPU to "
                          "rehearse the multi-process flow where RCCL refuses duplicate devices")
+    ap.add_argument("--rendezvous", choices=("socket", "gloo"), default="socket",
+                    help="N > 1: how the ranks meet on the host.  socket = a stdlib Unix-socket hub (no torch import: the run "
+                         "binds /opt/rocm's HIP runtime and librccl); gloo = torch.distributed (torch's bundled runtime loads first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the parity stamps (one extra step per leg, checked against the oracle, outside the timed regions)")
     ap.add_argument("--no-extras", action="store_true",
                     help="headline leg only: no repeats / alt_lds / extra_configs (1 GPU), no self_check / extra_configs (N GPUs)")
     ap.add_argument("--no-extra-configs", action="store_true",
@@ -395,25 +449,36 @@ def main():
 
     import nbody_amd as nb  # libnbody_hip.so is loaded at the first call; aborts later if no gfx950 answers
 
-    # torch.distributed only when launched through torch.distributed.run (also at world == 1, so that a
-    # single-GPU box can rehearse the whole multi-rank flow with NB_HIP_FORCE_SHARDED=1)
+    # The ranks meet on the host only when launched through torch.distributed.run (also at world == 1, so that a
+    # single-GPU box can rehearse the whole multi-rank flow with NB_HIP_FORCE_SHARDED=1): by default over a stdlib
+    # socket hub, so that no torch -- and with it no second HIP runtime / librccl -- is in the process.
     dist = None
     torch = None
+    link = None
     if "RANK" in os.environ and "MASTER_PORT" in os.environ:
-        import torch
-        import torch.distributed as dist
+        if args.rendezvous == "gloo":
+            import torch
+            import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=900))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=900))
+        else:
+            from nbody_amd.ranklink import RankLink
+
+            link = RankLink(rank, world)
     elif world > 1:
         sys.exit("WORLD_SIZE > 1 without a torch.distributed.run rendezvous (RANK / MASTER_PORT missing)")
 
     def barrier():
         if dist is not None:
             dist.barrier()
+        elif link is not None:
+            link.barrier()
 
     def reduce(values, op):
         """Element-wise MIN/MAX/SUM of a list of floats over the ranks."""
+        if link is not None:
+            return link.reduce(values, op)
         if dist is None:
             return list(values)
         t = torch.tensor(list(values), dtype=torch.float64)
@@ -421,24 +486,40 @@ def main():
         return [float(x) for x in t]
 
     def new_unique_id():
-        """rank 0 makes an RCCL unique id; gloo carries its 128 bytes to the other ranks."""
-        raw = bytearray(nb.comm_unique_id()) if rank == 0 else bytearray(nb.UNIQUE_ID_BYTES)
-        if dist is not None:
+        """rank 0 makes an RCCL unique id; the rendezvous carries its 128 bytes to the other ranks."""
+        if args.dry_run:   # no GPU: /opt/rocm's ncclGetUniqueId needs one; the hand-over is what is rehearsed
+            raw = bytearray(range(nb.UNIQUE_ID_BYTES)) if rank == 0 else bytearray(nb.UNIQUE_ID_BYTES)
+        else:
+            raw = bytearray(nb.comm_unique_id()) if rank == 0 else bytearray(nb.UNIQUE_ID_BYTES)
+        if link is not None:
+            raw = bytearray(link.broadcast(bytes(raw), src=0))
+        elif dist is not None:
             buf = torch.frombuffer(raw, dtype=torch.uint8).clone()
             dist.broadcast(buf, src=0)
             raw = bytearray(buf.numpy().tobytes())
-        assert len(raw) == nb.UNIQUE_ID_BYTES
+        assert len(raw) == nb.UNIQUE_ID_BYTES and (not args.dry_run or bytes(raw) == bytes(range(nb.UNIQUE_ID_BYTES)))
         return bytes(raw)
+
+    def digests_agree(digest):
+        """True when every rank's sha256 equals rank 0's."""
+        if link is not None:
+            return all(d == digest for d in link.allgather(bytes(digest)))
+        return _digests_agree(dist, torch, digest)
 
     current_leg = {"name": "headline"}
     gloo_gather = None
     if args.transport == "host" and sharded:
         def gloo_gather(rows, r, n):
-            """In-place all-gather of host rows over gloo (rows[r] is filled on entry)."""
+            """In-place all-gather of host rows over the rendezvous (rows[r] is filled on entry)."""
             if args.stall_leg and current_leg["name"] == args.stall_leg:
                 time.sleep(3600.0)   # rehearsal of a collective that never completes (--stall-leg)
             if args.crash_leg and current_leg["name"] == args.crash_leg and r == 0:
                 os.abort()           # rehearsal of a leg that dies by the library's abort() convention (--crash-leg)
+            if link is not None:
+                for q, row in enumerate(link.allgather(rows[r].tobytes())):
+                    if q != r:
+                        rows[q] = np.frombuffer(row, dtype=rows.dtype)
+                return
             if dist is None:
                 return
             mine = torch.from_numpy(rows[r].copy())
@@ -535,11 +616,14 @@ def main():
         shape = sim.launch_shape()
         info = nb.device_info()
         runtime = {"hip_runtime_version": int(nb.hip_lib().nb_hip_runtime_version()),
-                   "torch_imported_first": torch is not None}
+                   "torch_imported_first": torch is not None,
+                   "rendezvous": "gloo" if dist is not None else ("socket hub" if link is not None else None)}
         if sharded:
             extras["rccl"] = comm_evidence(sim)
             d = sharded_detail(sim, args.steps)
             extras["comm_ms_per_step"], extras["kernel_ms_per_step"] = d["comm_ms_per_step"], d["kernel_ms_per_step"]
+        elif not args.no_parity:
+            extras["parity"] = parity_stamp(sim, mass_len)   # after the timed call, outside it
 
     # ---- the JSON dict: complete from here on; later legs only add keys -----------------------------------------
     out = {}
@@ -607,7 +691,7 @@ def main():
                                 f", partitioned; N={n}, mass_len={mass_len}, "
                                 f"dt={DT}; {n * mass_len:.4g} interactions/step; one PerformSimUpdate({args.steps}) call",
                     "parallelism": (f"receivers sharded N/{world} per GPU, all-gather of source positions per step"
-                                    + (" over the caller-supplied HOST transport (gloo; rehearsal, not RCCL)" if gloo_gather else ""))
+                                    + (" over the caller-supplied HOST transport (rehearsal, not RCCL)" if gloo_gather else ""))
                                    if world > 1 else "single GPU",
                     "kernel": shape,
                     "device": info,
@@ -619,7 +703,7 @@ def main():
                 # ncclCommCount as seen by every rank's communicator -- null when a rank holds none (host transport, dry run)
                 out["rccl_nranks"] = (extras["rccl"]["nranks_reported"]["min"]
                                       if extras["rccl"]["ranks_with_communicator"] == world else None)
-                out["transport"] = ("host (gloo all-gather through page-locked staging)" if gloo_gather
+                out["transport"] = ("host (all-gather over the rendezvous link through page-locked staging)" if gloo_gather
                                     else "rccl (in-stream ncclAllGather)")
             out.update(extras)
             if cpu is not None:
@@ -645,7 +729,7 @@ def main():
 
         if args.dry_run:
             digest = hashlib.sha256(part.tobytes()).digest()
-            put("self_check", {"ranks_agree": _digests_agree(dist, torch, digest), "vs_single_gpu_rel_l2_pos": None})
+            put("self_check", {"ranks_agree": digests_agree(digest), "vs_single_gpu_rel_l2_pos": None})
             part5, m5 = make_workload(args.n5)
             _ = new_unique_id()
             p5 = nb.shard_plan(part5.shape[0], m5, rank, world)
@@ -660,7 +744,7 @@ def main():
             # every rank must hold the same full state, and it must be the single-GPU state of the same steps
             leg("self_check")
             got = sim.get_data()  # collective
-            check = {"ranks_agree": _digests_agree(dist, torch, hashlib.sha256(got.tobytes()).digest()),
+            check = {"ranks_agree": digests_agree(hashlib.sha256(got.tobytes()).digest()),
                      "steps": steps_done}
             if rank == 0:
                 one = nb.SimPipeline(n, mass_len)
@@ -733,7 +817,7 @@ def main():
         sim.close()
         sim = None
         if not args.all_massive and args.n == N_PARTICLES and not args.no_extra_configs:
-            put("extra_configs", single_gpu_configs(nb))
+            put("extra_configs", single_gpu_configs(nb, stamp=not args.no_parity))
     if sim is not None:
         sim.close()
 
@@ -742,10 +826,14 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if link is not None:
+        link.barrier()
+        link.close()
 
 
-def single_gpu_configs(nb):
-    """BASELINE.json's other single-GPU configurations, in the shape of the reference harness (src/bench.c:21-35)."""
+def single_gpu_configs(nb, stamp=True):
+    """BASELINE.json's other single-GPU configurations, in the shape of the reference harness (src/bench.c:21-35), and
+    the all-massive (N^2) run SURVEY.md 8d asks to report beside the headline."""
     out = []
 
     def rate(n, m, sec_per_step):
@@ -775,6 +863,8 @@ def single_gpu_configs(nb):
              "launches": launches, "graph_stats": sim.graph_stats()}
     entry.update(rate(n, m, first))
     entry["later_calls"] = dict(rate(n, m, min(later)), note="fastest of 3 further 100-step calls (cached hipGraph replays)")
+    if stamp:
+        entry["parity"] = parity_stamp(sim, m)
     sim.close()
     out.append(entry)
 
@@ -803,6 +893,30 @@ def single_gpu_configs(nb):
              "chain_rebuilt_for_new_dt": g1["cached"] != g0["cached"], "dt_uploads_for_new_dt": g1["dt_uploads"] - g0["dt_uploads"]}
     entry.update(rate(n, m, at_dt))
     entry["dt_halved"] = rate(n, m, at_half)
+    if stamp:
+        entry["parity"] = parity_stamp(sim, m, dt=DT / 2)
+    sim.close()
+    out.append(entry)
+
+    # N2: the all-massive run (SURVEY.md 8d "also report the all-massive equivalent"): the same universe with the massless
+    # half given the mass galaxy.h would give a body of its radius, so every particle is a source: N x N interactions
+    part, m = make_workload(N_PARTICLES, all_massive=True)
+    n = part.shape[0]
+    sim = nb.SimPipeline(n, m)
+    sim.configure(graph=1)
+    sim.set_data(part)
+    k = 4
+    sim.update(1, DT)
+    t0 = time.perf_counter()
+    sim.update(k, DT)
+    sec = (time.perf_counter() - t0) / k
+    k_ms, launches = sim.last_step_ms()
+    entry = {"config": "N2", "workload": f"srand(11037) MakeGalaxies({n}, 2), massless half given NP_R_TO_M(radius) mass: N={n}, "
+                                         f"mass_len={m}, dt={DT}; {float(n) * m:.4g} interactions/step; one PerformSimUpdate({k}) call",
+             "steps": k, "kernel": sim.launch_shape(), "kernel_ms_per_launch": k_ms / max(launches, 1), "launches": launches}
+    entry.update(rate(n, m, sec))
+    if stamp:
+        entry["parity"] = parity_stamp(sim, m)
     sim.close()
     out.append(entry)
 

@@ -28,17 +28,18 @@ def test_sharded_exchange_reproduces_single_rank(tmp_path, golden, world, n):
     assert got.tobytes() == want.tobytes()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_bench_multi_rank_control_flow_dry_run(world):
-    """bench.py under torch.distributed.run, world_size > 1, no GPU: rendezvous, RCCL-id broadcast over gloo,
-    barriers, max-over-ranks reduction and the one JSON line on rank 0 (the sharded device work is skipped)."""
+@pytest.mark.parametrize("world,rendezvous", [(2, "socket"), (3, "socket"), (2, "gloo")])
+def test_bench_multi_rank_control_flow_dry_run(world, rendezvous):
+    """bench.py under torch.distributed.run, world_size > 1, no GPU: rendezvous (the stdlib socket hub by default, gloo on
+    request), RCCL-id broadcast, barriers, max-over-ranks reduction and the one JSON line on rank 0 (the sharded device
+    work is skipped)."""
     import json
     root = os.path.dirname(HERE)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", str(29610 + world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29610 + world + (10 if rendezvous == "gloo" else 0)),
            os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--particles", "65536",
-           "--extra-particles", "131072", "--dry-run"]
+           "--extra-particles", "131072", "--dry-run", "--rendezvous", rendezvous]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -150,3 +151,35 @@ def test_bench_leg_guard_deadline_writes_the_line_and_exits():
     assert "passed its deadline" in r0.stderr
     r1 = subprocess.run([sys.executable, "-c", code, "1"], capture_output=True, text=True, timeout=120)
     assert r1.returncode == 4 and r1.stdout == ""
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_rank_link_collectives_with_real_processes(world, tmp_path):
+    """nbody_amd/ranklink.py: `world` processes meet over the abstract Unix socket, then all-gather, broadcast, reduce and
+    barrier; no torch in the workers (asserted: importing it is what the link exists to avoid)."""
+    root = os.path.dirname(HERE)
+    code = f"""
+import sys
+sys.path.insert(0, {root!r})
+from nbody_amd.ranklink import RankLink
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+link = RankLink(rank, world, name="nbody_test_{os.getpid()}_" + sys.argv[2], timeout_s=60)
+assert link.allgather(("r", rank)) == [("r", q) for q in range(world)]
+assert link.broadcast(b"x" * 128 if rank == 0 else None) == b"x" * 128
+assert link.reduce([rank, -rank, 1.0], "max") == [world - 1.0, 0.0, 1.0]
+assert link.reduce([rank, -rank, 1.0], "min") == [0.0, -(world - 1.0), 1.0]
+assert link.reduce([rank, 2.0], "sum") == [world * (world - 1) / 2.0, 2.0 * world]
+big = bytes([rank]) * (3 << 20)
+rows = link.allgather(big)
+assert [len(r) for r in rows] == [3 << 20] * world and all(rows[q][:1] == bytes([q]) for q in range(world))
+for _ in range(100):
+    link.barrier()
+link.close()
+assert "torch" not in sys.modules
+print("ok", rank)
+"""
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(world)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert sorted(o[0].strip() for o in outs) == [f"ok {r}" for r in range(world)]
