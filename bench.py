@@ -316,37 +316,24 @@ def algorithmic_bytes_per_launch(n, m, passes):
 class LastGasp:
     """The optional legs can also die the hard way: the library's error convention is the reference's -- print and abort()
     (src/lib/util.h:17-29) -- and RCCL inside stream capture with several ranks has never run anywhere.  A fatal signal
-    raised inside a C call never reaches a Python-level handler, so rank 0 registers a C-level one (a ctypes callback handed
-    to libc's signal()) for SIGABRT / SIGSEGV / SIGBUS / SIGFPE while optional legs run: it writes the line prepared when
-    the current leg was armed -- headline + self-check + the legs finished so far + "extras_aborted" -- and leaves with
-    os._exit(6).  One write of bytes serialised beforehand; nothing else happens in signal context."""
-
-    SIGNALS = (6, 11, 7, 8)   # SIGABRT, SIGSEGV, SIGBUS, SIGFPE
+    raised inside a C call never reaches a Python-level handler, so rank 0 registers a C one while optional legs run
+    (nbody_amd/csrc/last_gasp.c -> lib/libnb_lastgasp.so): on SIGABRT / SIGSEGV / SIGBUS / SIGFPE it write()s the line
+    prepared when the current leg was armed -- headline + self-check + the legs finished so far + "extras_aborted" -- and
+    _exit(6)s.  The handler is plain C doing only async-signal-safe calls on bytes copied beforehand: no GIL, no
+    allocation, no Python in signal context."""
 
     def __init__(self, fd):
-        self.fd, self.line, self.done = fd, None, False
-        self._libc = C.CDLL(None, use_errno=True)
-        self._proto = C.CFUNCTYPE(None, C.c_int)
-        self._handler = self._proto(self._on_signal)   # must outlive the registration
-        self._libc.signal.restype = C.c_void_p
-        self._libc.signal.argtypes = [C.c_int, self._proto]
+        self.fd = fd
+        self._lib = C.CDLL(os.path.join(ROOT, "nbody_amd", "lib", "libnb_lastgasp.so"))
+        self._lib.nb_last_gasp_set.argtypes = [C.c_int, C.c_char_p, C.c_ulong]
+        self._lib.nb_last_gasp_set.restype = C.c_int
 
     def arm(self, line_bytes):
-        first = self.line is None
-        self.line = line_bytes
-        if first:
-            for sig in self.SIGNALS:
-                self._libc.signal(sig, self._handler)
+        if self._lib.nb_last_gasp_set(self.fd, line_bytes, len(line_bytes)) != 0:
+            print("[bench] last-gasp line too long; keeping the previous one", file=sys.stderr)
 
     def disarm(self):
-        self.done = True
-
-    def _on_signal(self, sig):
-        if not self.done and self.line is not None:
-            self.done = True
-            os.write(self.fd, self.line)
-            os.write(2, f"[bench] fatal signal {sig} inside an optional leg; the line written holds what was in hand (exit 6)\n".encode())
-        os._exit(6)
+        self._lib.nb_last_gasp_disarm()
 
 
 class LegGuard:

@@ -101,6 +101,8 @@ inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 // pipeline (PerformSimUpdate's sync, the collective GetSimulationData) -- runs under a watchdog that prints what was
 // being waited for, the tail of RCCL's own log when NCCL_DEBUG_FILE names one, and _exit(3)s.  No retry and no
 // re-exec: the process has initialised the GPU.  NB_HIP_COMM_TIMEOUT_S (default 180) sets the bound; 0 disables it.
+// One long-lived thread per process does the watching; a Watchdog object only arms it with a deadline and disarms it
+// again (a mutex and a notify: a frame loop of short sharded calls does not pay a thread spawn + join per sync).
 class Watchdog {
   public:
     Watchdog(const char *what, int rank, int nranks);
@@ -109,13 +111,7 @@ class Watchdog {
     Watchdog &operator=(const Watchdog &) = delete;
 
   private:
-    void run();
-    const char *what_;
-    int rank_, nranks_, seconds_ = 0;
-    bool done_ = false;
-    std::mutex m_;
-    std::condition_variable cv_;
-    std::thread th_;
+    bool armed_ = false;
 };
 
 // ncclCommInitRank + cross-check of the communicator's own rank count + a verified probe all-gather, all bounded

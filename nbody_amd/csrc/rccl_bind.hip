@@ -74,42 +74,90 @@ Rccl &rccl() {
 
 namespace nbi {
 
-Watchdog::Watchdog(const char *what, int rank, int nranks) : what_(what), rank_(rank), nranks_(nranks) {
+namespace {
+
+// the process' one watcher thread: sleeps until armed, then until the deadline or the disarm, whichever comes first
+struct Watcher {
+    std::mutex m;
+    std::condition_variable cv;
+    std::thread th;
+    bool started = false;
+    uint64_t armed_seq = 0;   // 0 = idle; otherwise the id of the wait being watched
+    uint64_t next_seq = 1;
+    std::chrono::steady_clock::time_point deadline;
+    const char *what = "";
+    int rank = 0, nranks = 1, seconds = 0;
+
+    void run() {
+        std::unique_lock<std::mutex> l(m);
+        for (;;) {
+            cv.wait(l, [this] { return armed_seq != 0; });
+            const uint64_t watching = armed_seq;
+            if (cv.wait_until(l, deadline, [&] { return armed_seq != watching; })) continue;  // disarmed (or re-armed) in time
+            give_up();
+        }
+    }
+
+    [[noreturn]] void give_up() {
+        fprintf(stderr, "%s [watchdog] rank %d of %d: %s did not complete within %d s; giving up (exit 3)\n", __FILE__, rank, nranks, what,
+                seconds);
+        const char *log = getenv("NCCL_DEBUG_FILE");
+        if (log && !strchr(log, '%')) {
+            if (FILE *f = fopen(log, "r")) {
+                fseek(f, 0, SEEK_END);
+                long sz = ftell(f);
+                fseek(f, sz > 4096 ? sz - 4096 : 0, SEEK_SET);
+                char buf[4097];
+                size_t got = fread(buf, 1, 4096, f);
+                buf[got] = 0;
+                fprintf(stderr, "---- tail of %s ----\n%s\n", log, buf);
+                fclose(f);
+            }
+        }
+        fflush(stderr);
+        _exit(3);
+    }
+};
+
+Watcher &watcher() {
+    static Watcher *w = new Watcher();  // never destroyed: the thread may outlive static destruction
+    return *w;
+}
+
+}  // namespace
+
+Watchdog::Watchdog(const char *what, int rank, int nranks) {
     const char *t = getenv("NB_HIP_COMM_TIMEOUT_S");
-    seconds_ = t ? atoi(t) : 180;
-    if (seconds_ > 0) th_ = std::thread([this] { run(); });
+    const int seconds = t ? atoi(t) : 180;
+    if (seconds <= 0) return;
+    Watcher &w = watcher();
+    {
+        std::lock_guard<std::mutex> l(w.m);
+        if (w.armed_seq != 0) return;  // an outer wait is already being watched: its deadline stands
+        if (!w.started) {
+            w.started = true;
+            w.th = std::thread([&w] { w.run(); });
+            w.th.detach();
+        }
+        w.what = what;
+        w.rank = rank;
+        w.nranks = nranks;
+        w.seconds = seconds;
+        w.deadline = std::chrono::steady_clock::now() + std::chrono::seconds(seconds);
+        w.armed_seq = w.next_seq++;
+        armed_ = true;
+    }
+    w.cv.notify_all();
 }
 
 Watchdog::~Watchdog() {
-    if (!th_.joinable()) return;
+    if (!armed_) return;
+    Watcher &w = watcher();
     {
-        std::lock_guard<std::mutex> l(m_);
-        done_ = true;
+        std::lock_guard<std::mutex> l(w.m);
+        w.armed_seq = 0;
     }
-    cv_.notify_all();
-    th_.join();
-}
-
-void Watchdog::run() {
-    std::unique_lock<std::mutex> l(m_);
-    if (cv_.wait_for(l, std::chrono::seconds(seconds_), [this] { return done_; })) return;
-    fprintf(stderr, "%s [watchdog] rank %d of %d: %s did not complete within %d s; giving up (exit 3)\n", __FILE__, rank_,
-            nranks_, what_, seconds_);
-    const char *log = getenv("NCCL_DEBUG_FILE");
-    if (log && !strchr(log, '%')) {
-        if (FILE *f = fopen(log, "r")) {
-            fseek(f, 0, SEEK_END);
-            long sz = ftell(f);
-            fseek(f, sz > 4096 ? sz - 4096 : 0, SEEK_SET);
-            char buf[4097];
-            size_t got = fread(buf, 1, 4096, f);
-            buf[got] = 0;
-            fprintf(stderr, "---- tail of %s ----\n%s\n", log, buf);
-            fclose(f);
-        }
-    }
-    fflush(stderr);
-    _exit(3);
+    w.cv.notify_all();
 }
 
 void comm_create(SimPipeline *s, const void *unique_id128) {

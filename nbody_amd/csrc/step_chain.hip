@@ -275,7 +275,9 @@ constexpr uint32_t CHAIN_MAX_STEPS_PER_LAUNCH = 1u << 16;
 bool wants_fused_chain(const SimPipeline *s) {
     if (s->sharded || s->fused_chain == 0 || s->n_real == 0 || nb::chain_tiles(s->n_real) == 0) return false;
     if (s->fused_chain == 1) return true;
-    const bool shape_on_auto = s->want_k == 0 && s->want_w == 0 && s->want_split == 0 && s->want_unit == 0 && s->want_passes == 0;
+    // an explicit k / w / split / unit / passes / lanes / route asks for the per-step kernel (choose_shape treats them so too)
+    const bool shape_on_auto = s->want_k == 0 && s->want_w == 0 && s->want_split == 0 && s->want_unit == 0 && s->want_passes == 0 &&
+                               s->want_lanes == 0 && s->want_variant == nb::VARIANT_SMEM;
     return shape_on_auto && s->n_real <= CHAIN_AUTO_MAX_RECV && (double)s->n_real * (double)(s->n_src ? s->n_src : 1) <= CHAIN_MAX_PAIRS;
 }
 
