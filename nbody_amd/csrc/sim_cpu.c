@@ -16,6 +16,9 @@
  * SIMD_SET, like the reference's CMake option (CMakeLists.txt:4, src/lib/CMakeLists.txt:24-33): the default
  * build is AVX (8 lanes); -DNB_SIMD_SSE gives the reference's SSE build (4 lanes), -DNB_SIMD_NONE its scalar
  * build (1 lane = sources in index order).  Each is bit-exact with the corresponding reference build.
+ * -DNB_SIMD_F64 (SIMD_SET=f64, no reference counterpart) is the "truth" mode: every term
+ * and the sum in float64 from the same fp32 inputs, sources in index order, the sum rounded once to the fp32 acc; the
+ * integrator stays the reference's fp32 mul-then-add.  It is the tie-breaker the fp32 tolerance is stated against.
  *
  * Build: -mavx -ffp-contract=off (no FMA contraction), see csrc/Makefile.
  */
@@ -35,6 +38,19 @@ typedef __m128 vf;
 #define vf_mul _mm_mul_ps
 #define vf_div _mm_div_ps
 #define vf_sqrt _mm_sqrt_ps
+#elif defined(NB_SIMD_F64)
+#include <math.h>
+#define V 1u
+typedef double vf;
+#define vf_set1(x) ((double)(x))
+#define vf_zero() 0.0
+#define vf_load(p) ((double)*(p))
+#define vf_storeu(p, x) (*(p) = (float)(x))
+#define vf_add(a, b) ((a) + (b))
+#define vf_sub(a, b) ((a) - (b))
+#define vf_mul(a, b) ((a) * (b))
+#define vf_div(a, b) ((a) / (b))
+#define vf_sqrt(a) sqrt(a)
 #elif defined(NB_SIMD_NONE)
 #include <math.h>
 #define V 1u

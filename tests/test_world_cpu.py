@@ -201,3 +201,32 @@ def test_other_simd_set_builds_match_their_reference_builds(manifest, golden, na
         assert ob.sha256(got) == e["sha256"], tag
         seen += 1
     assert seen == 4
+
+
+@pytest.mark.parametrize("n", [333, 4096])
+def test_float64_truth_build_of_the_cpu_stepper(golden, n):
+    """SIMD_SET=f64 (libnbody_f64.so): every term and the sum in float64 from the fp32 inputs, one
+    rounding to the fp32 acc, then the reference's fp32 integrator.  The acc equals the oracle's float64 sum rounded to
+    fp32 bit for bit, and sits within the stated tolerance of the AVX build's -- the tie-breaker the tolerance names."""
+    nb.hip_lib()
+    lib = C.CDLL(os.path.join(nb.LIB_DIR, "libnbody_f64.so"))
+    lib.CreateWorld.restype = C.c_void_p
+    lib.CreateWorld.argtypes = [C.c_void_p, C.c_uint32]
+    lib.GetWorldParticles.restype = C.c_void_p
+    lib.GetWorldParticles.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    lib.UpdateWorld_CPU.argtypes = [C.c_void_p, C.c_float, C.c_uint32]
+    lib.DestroyWorld.argtypes = [C.c_void_p]
+    ic = golden(f"ic_{n}.bin")
+    part, m = ob.partition(ic)
+    w = lib.CreateWorld(ic.ctypes.data, n)
+    lib.UpdateWorld_CPU(w, 0.01, 1)
+    cnt = C.c_uint32()
+    p = lib.GetWorldParticles(w, C.byref(cnt))
+    got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(cnt.value, 8)).copy()
+    lib.DestroyWorld(w)
+    acc64, mag = ob.acc_f64(part, m)
+    assert np.array_equal(got[:, 4:6], acc64.astype(np.float32))
+    v = part[:, 2:4] + got[:, 4:6] * np.float32(0.01)
+    assert np.array_equal(got[:, 2:4], v) and np.array_equal(got[:, 0:2], part[:, 0:2] + v * np.float32(0.01))
+    avx = ob.step(part, m, 0.01, 1)
+    assert np.all(np.abs(avx[:, 4:6].astype(np.float64) - acc64) <= 1e-4 * np.abs(acc64) + 1e-6 * mag)
