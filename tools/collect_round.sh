@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): everything profiles/<tag>_* is made from, except the rocprofv3 passes
-# (tools/profile.sh, tools/profile_routes.sh, tools/profile_mid_n.sh).  usage: tools/collect_round.sh r03 [full]
+# (tools/profile.sh, tools/profile_routes.sh, tools/profile_mid_n.sh).  usage: tools/collect_round.sh r04 [full]
 # "full" adds the frame-loop / graph-policy probes of round 2 (frozen since: the GUI they serve is out of scope).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 FULL=${2:-}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
@@ -11,7 +11,9 @@ cd $R
 python -m pytest tests -m gpu -q --timeout 900 --timeout-method=thread > $O/${TAG}_pytest_gpu.txt 2>&1; echo "pytest rc=$?"
 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"
 NB_HIP_FORCE_SHARDED=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
-    bench.py --gpus 1 --steps 10 --warmup 2 > $O/${TAG}_rehearsal_1rank.json 2> $O/${TAG}_rehearsal_1rank.err; echo "rehearsal rc=$?"
+    bench.py --gpus 1 --steps 10 --warmup 2 > $O/${TAG}_rehearsal_1rank.json 2> $O/${TAG}_rehearsal_1rank.err; echo "rehearsal (socket rendezvous, /opt/rocm runtime) rc=$?"
+NB_HIP_FORCE_SHARDED=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 \
+    bench.py --gpus 1 --steps 10 --warmup 2 --rendezvous gloo > $O/${TAG}_rehearsal_1rank_gloo.json 2> $O/${TAG}_rehearsal_1rank_gloo.err; echo "rehearsal (gloo: torch's runtime first) rc=$?"
 {
   echo "== nbody_amd/lib/nbody-bench (reference harness defaults: srand(11037), 10 warm-up + 100 steps, dt = 1; us/step), MI355X box, OMP_NUM_THREADS=16 =="
   OMP_NUM_THREADS=16 ./nbody_amd/lib/nbody-bench
@@ -27,6 +29,18 @@ for P in 2 3; do
   python -m torch.distributed.run --nnodes=1 --nproc-per-node $P --master-addr 127.0.0.1 --master-port 2954$P bench.py --gpus $P \
       --transport host --steps 10 --warmup 2 > $O/${TAG}_rehearsal_${P}ranks_host.json 2> $O/${TAG}_rehearsal_${P}ranks_host.err; echo "host-transport P=$P rc=$?"
 done
+# round 4: the C harness' own multi-process mode (ranks forked before any HIP call, shared page, no Python / torch)
+{
+  echo "== nbody-bench --gpus 1 --force-sharded --n 20000 --n 1048576 --steps 10 --warmup 2 --dt 0.01: the RCCL path with one rank (ncclCommInitRank, in-place ncclAllGather per step, overlapped step, chain captured as a hipGraph) on /opt/rocm's HIP runtime + librccl =="
+  ./nbody_amd/lib/nbody-bench --gpus 1 --force-sharded --n 20000 --n 1048576 --steps 10 --warmup 2 --dt 0.01
+  for P in 2 3; do
+    echo
+    echo "== nbody-bench --gpus $P --transport shm --n 4096 --n 65536 --n 1048576 --steps 10 --warmup 2 --dt 0.01: $P real C processes on ONE MI355X (host-staged exchange over the shared page; all ranks share the GPU, so the rate is one GPU's) =="
+    ./nbody_amd/lib/nbody-bench --gpus $P --transport shm --n 4096 --n 65536 --n 1048576 --steps 10 --warmup 2 --dt 0.01
+  done
+} > $O/${TAG}_nbody_bench_ranks.txt 2>&1; echo "C ranks rc=$?"
+python tools/gpu_vs_avx.py > $O/${TAG}_gpu_vs_avx.txt 2>&1; echo "gpu-vs-avx rc=$?"
+python -m pytest tests/test_gpu_parity.py -q -s -m gpu -k near_the_best > $O/${TAG}_auto_vs_neighbours.txt 2>&1; echo "auto-vs-neighbours rc=$?"
 [ "$FULL" = "full" ] || exit 0
 {
   echo "== tools/frame_probe.py: the reference GUI's frame loop through include/nbody.h (300 frames each), defaults =="
