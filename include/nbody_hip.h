@@ -147,7 +147,8 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
 
 /*
  * Tuning knobs.  key is one of:
- *   "variant"   0 = wave-private LDS tiles, 1 = scalar-cache (SMEM) source broadcast (default: measured 2.5 % faster)
+ *   "variant"   0 = wave-private LDS tiles, 1 = scalar-cache (SMEM) source broadcast (default: 8 % faster at N = 2^20,
+ *               every bench.py line times both: roofline.alt_lds)
  *   "k"         receivers per lane: 0 = auto, else 1 or 2 (4 only in TUNING=1 builds)
  *   "w"         waves (source slices) per workgroup: 0 = auto (4, 8 or 16), else 1, 4, 8 or 16 (2 only in TUNING=1
  *               builds); w = 1 makes the summation order independent of the launch geometry
@@ -195,7 +196,11 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
  *   "sharded_graph"  sharded pipelines: 1 = capture the {kernel, all-gather} x n chain into a hipGraph and replay
  *               it (non-overlapped step only); 0 = plain stream launches (default)
  *   "overlap"   sharded pipelines: 1 = split each step into own-shard / remote-shard kernels
- *               with the all-gather in between on a second stream, 0 = gather then one kernel
+ *               with the all-gather in between on a second stream, 0 = gather then one kernel (default)
+ *               Both are opt-in by policy: per rank a step is O(N*M/P) of kernel against an O(M)
+ *               gather -- <= 0.5 % of a step at the BASELINE sizes -- so neither can pay there, RCCL with more than one rank
+ *               (and RCCL inside stream capture) has never run here, and every harness times all three modes from one
+ *               command so that the first multi-GPU run decides with numbers
  * Returns the previous value; aborts on an unknown key or value.
  */
 int nb_hip_configure(SimPipeline *sim, const char *key, int value);

@@ -221,7 +221,7 @@ struct SimPipeline {
     uint64_t use_clock = 0;     // ticks once per graph lookup (LRU)
 
     // knobs
-    int want_variant = nb::VARIANT_SMEM, want_k = 0, want_w = 0, want_split = 0;  // SMEM measures 5-8 % faster than LDS tiles
+    int want_variant = nb::VARIANT_SMEM, want_k = 0, want_w = 0, want_split = 0;  // the scalar-cache route is 8 % faster than LDS tiles at N = 2^20 (roofline.alt_lds)
     int use_graph = 2, overlap = 0, sharded_graph = 0;  // use_graph: 0 never, 1 always, 2 from a chain length's second use
     int fused_chain = 2;                                // one-launch n-step chains for one-workgroup worlds: 0 never, 2 auto
     std::vector<uint32_t> seen_chains;                  // chain lengths already run once as plain launches

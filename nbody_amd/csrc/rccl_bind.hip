@@ -1,8 +1,9 @@
 // rccl_bind.hip -- RCCL for the sharded pipeline: the library bound lazily, the communicator, the watchdog.
 //
 // The reference has no counterpart (one device, vulkan_ctx.c:83-84).  librccl is ~0.5 GB, so it is dlopen'ed on first
-// use and single-GPU users never load it; under torch.distributed.run the soname resolves to the copy torch already
-// loaded.  Only five entry points of the data path are used: ncclGetUniqueId, ncclCommInitRank,
+// use and single-GPU users never load it.  The soname resolves to whatever copy the process already holds: /opt/rocm's in
+// nbody-bench and in bench.py (neither imports torch), the torch wheel's in a process that imported torch first
+// (DESIGN.md section 4).  Only five entry points of the data path are used: ncclGetUniqueId, ncclCommInitRank,
 // ncclAllGather (in place, float32), ncclCommDestroy, plus the introspection calls a multi-GPU run reports.
 #include <dlfcn.h>
 #include <unistd.h>

@@ -167,7 +167,9 @@ def test_lane_split_rule_matches_the_committed_scan():
     for n, m in ((5000, 2439), (10000, 4917), (20000, 9956), (65536, 32641), (1 << 20, 523884), (100, 0), (0, 0)):
         assert nb.plan_launch(n, m)["lanes"] == 1, (n, m)
     # the committed scan really says so: at every scanned size up to N = 4 000 some lane-split shape beats the classic
-    # auto shape, and from N = 5 000 on none does
+    # auto shape; from N = 5 000 on none does EXCEPT the N = 6 000 row, where lanes = 4, w = 16 edges the classic pick out
+    # by ~2 % while its neighbours 5 000 and 8 000 lose -- a non-monotonic row the rule's 9e6-pair cut-off deliberately
+    # does not chase
     import re
     text = open(os.path.join(ROOT, "profiles", "r03_lane_split_scan.txt")).read()
     block = text[text.index("== the shipped (tiled) kernel"):text.index("== the shipped kernel (velocity")]
