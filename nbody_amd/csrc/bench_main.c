@@ -363,9 +363,10 @@ static int run_rank(const Options *o, NbRankPage *pg) {
                 const double nr_min = nb_rank_reduce(pg, (double)nr, 'n'), nr_max = nb_rank_reduce(pg, (double)nr, 'x');
                 const double rk_sum = nb_rank_reduce(pg, (double)rk, 's');
                 if (rank == 0)
-                    fprintf(stderr, "nbody-bench: %d ranks, transport %s; ranks_with_communicator=%d ncclCommCount=%d..%d user_rank_sum=%d "
+                    fprintf(stderr, "nbody-bench: %d ranks, transport %s; ranks_with_communicator=%d %s=%d..%d user_rank_sum=%d "
                             "rccl=%d lib=%s first_gather_ms=%.3f; HIP runtime %d\n", P, o->transport_shm ? "shm" : "rccl", (int)owners,
-                            (int)nr_min, (int)nr_max, (int)rk_sum, ver, lib, first_ms, nb_hip_runtime_version());
+                            (int)owners == P ? "ncclCommCount" : "nranks_argument", (int)nr_min, (int)nr_max, (int)rk_sum, ver, lib, first_ms,
+                            nb_hip_runtime_version());
                 if (!o->transport_shm && ((int)owners != P || (int)nr_min != P || (int)nr_max != P || (int)rk_sum != P * (P - 1) / 2)) bad = 1;
             }
             if (rank == 0) {
