@@ -106,6 +106,13 @@ typedef void (*NbAllGatherFn)(void *ctx, void *buf, uint64_t bytes_per_rank, int
 World *CreateWorldShardedWith(const Particle *ps, uint32_t size, int rank, int nranks, NbAllGatherFn allgather, void *ctx);
 
 /*
+ * Extension: the sharded World over the direct exchange (CreateSimPipelineShardedDirect, include/nbody_hip.h): each rank
+ * pushes its slice device-to-device into every peer's IPC-mapped source array, `control` carries only handles and the
+ * per-step barrier.  DestroyWorld is a collective for such Worlds.
+ */
+World *CreateWorldShardedDirect(const Particle *ps, uint32_t size, int rank, int nranks, NbAllGatherFn control, void *ctx);
+
+/*
  * Extension: the HIP pipeline behind a World (include/nbody_hip.h), for tooling that wants its knobs and timers
  * (nb_hip_configure, nb_hip_last_step_ms, nb_hip_comm_info ...).  Owned by the World; never destroy it.
  */

@@ -262,6 +262,21 @@ SimPipeline *CreateSimPipelineSharded(WorldData data, int rank, int nranks, cons
 /* NbAllGatherFn: include/nbody.h -- void (*)(void *ctx, void *buf, uint64_t bytes_per_rank, int rank, int nranks) */
 SimPipeline *CreateSimPipelineShardedWith(WorldData data, int rank, int nranks, NbAllGatherFn allgather, void *ctx);
 
+/*
+ * The same sharded pipeline with the DIRECT exchange: no RCCL, no host staging of the data.  Every rank maps every
+ * peer's gathered source array (hipIpcGetMemHandle / hipIpcOpenMemHandle, exchanged once through `control`) and, after
+ * each step, copies its own slice device-to-device straight into all of them -- on xGMI, which is point-to-point, each of
+ * the P - 1 copies rides its own link: the direct all-gather, where a ring would serialise P - 1 hops per link -- then
+ * synchronises its stream and meets the other ranks in ONE host-side barrier per step (an 8-byte all-gather of step
+ * counters through `control`; every rank must be at the same step or the call aborts).  `control` is the same in-place
+ * host all-gather callback as above; it carries the IPC handles at the first SetSimulationData, the per-step barrier, the
+ * particle slices of a collective GetSimulationData, and one barrier in DestroySimPipeline (which is therefore a
+ * collective for these pipelines: nobody unmaps or frees while a peer may still write).  Costs a host round trip per
+ * step like the host transport (no hipGraph capture, no overlap gain) but moves no particle data through the host:
+ * a fallback for machines without a working RCCL and a way to run P processes on ONE device at device speed.
+ */
+SimPipeline *CreateSimPipelineShardedDirect(WorldData data, int rank, int nranks, NbAllGatherFn control, void *ctx);
+
 /* The shard arithmetic, pure host code (usable without a GPU). */
 typedef struct NbShardPlan {
     uint32_t mass_chunk;   /* Mc: massive slots per rank = all-gather count (uniform)   */

@@ -79,6 +79,7 @@ HIP_API = {
     "nb_hip_comm_unique_id": (None, [C.c_void_p]),
     "CreateSimPipelineSharded": (C.c_void_p, [WorldData, C.c_int, C.c_int, C.c_void_p]),
     "CreateSimPipelineShardedWith": (C.c_void_p, [WorldData, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]),
+    "CreateSimPipelineShardedDirect": (C.c_void_p, [WorldData, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]),
     "nb_hip_shard_plan": (NbShardPlan, [C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
     "nb_hip_local_group_create": (C.c_int, [WorldData, C.c_int, C.POINTER(C.c_void_p)]),
     "nb_hip_local_group_step": (None, [C.POINTER(C.c_void_p), C.c_int, C.c_uint32, C.c_float]),
@@ -94,6 +95,7 @@ NBODY_API = {
     "UpdateWorld_GPU": (None, [C.c_void_p, C.c_float, C.c_uint32]),
     "CreateWorldSharded": (C.c_void_p, [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
     "CreateWorldShardedWith": (C.c_void_p, [C.c_void_p, C.c_uint32, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]),
+    "CreateWorldShardedDirect": (C.c_void_p, [C.c_void_p, C.c_uint32, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]),
     "GetWorldPipeline": (C.c_void_p, [C.c_void_p]),
     "MakeGalaxies": (C.c_void_p, [C.c_uint32, C.c_uint32]),
     "MakeGalaxiesSeeded": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_uint64]),
@@ -189,9 +191,11 @@ class SimPipeline:
     `mass_len` massive ones, exactly what reference src/lib/world.c:32-58 hands its backend.
     """
 
-    def __init__(self, total_len, mass_len, rank=0, nranks=1, unique_id=None, allgather=None):
+    def __init__(self, total_len, mass_len, rank=0, nranks=1, unique_id=None, allgather=None, direct=False):
         """allgather: a Python callable (buf: writable uint8 array of shape (nranks, bytes_per_rank), rank, nranks) that
-        fills every row with its owner's bytes -- the caller-supplied host transport (CreateSimPipelineShardedWith)."""
+        fills every row with its owner's bytes -- the caller-supplied host transport (CreateSimPipelineShardedWith);
+        direct=True: the same callable carries only IPC handles and step barriers, the data goes device to device
+        (CreateSimPipelineShardedDirect)."""
         L = hip_lib()
         wd = WorldData(total_len, mass_len, 0.0)
         self._cb = None
@@ -211,7 +215,8 @@ class SimPipeline:
                           flush=True)
                     os._exit(5)
             self._cb = ALLGATHER_FN(thunk)   # must outlive the pipeline
-            self._h = L.CreateSimPipelineShardedWith(wd, rank, nranks, self._cb, None)
+            create = L.CreateSimPipelineShardedDirect if direct else L.CreateSimPipelineShardedWith
+            self._h = create(wd, rank, nranks, self._cb, None)
         elif nranks > 1 or unique_id is not None:
             idbuf = (C.c_ubyte * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
             self._h = L.CreateSimPipelineSharded(wd, rank, nranks, idbuf)

@@ -32,8 +32,12 @@
  *   --gpus P           fork P ranks BEFORE anything touches HIP; rank r drives device r; the ranks share one
  *                      anonymous MAP_SHARED page (rank_page.h) for barriers, the max-over-ranks time and RCCL's unique id
  *   --transport T      rccl (default): CreateWorldSharded, per-step in-place ncclAllGather over xGMI inside the library;
- *                      shm: CreateWorldShardedWith over the shared page (host-staged) -- lets P ranks share ONE GPU, where
- *                      RCCL refuses duplicate devices, to exercise the whole multi-process path on a one-GPU box
+ *                      ipc: CreateWorldShardedDirect -- no RCCL: every rank maps its peers' source arrays (hipIpc handles passed
+ *                      through the page) and pushes its slice device-to-device into each after every step (on xGMI one copy per
+ *                      link), then ONE host barrier per step at the page; the fallback should RCCL not come up;
+ *                      shm: CreateWorldShardedWith over the shared page (host-staged data).
+ *                      ipc and shm let P ranks share ONE GPU (rank r drives device r mod visible devices), where RCCL refuses
+ *                      duplicate devices: the whole multi-process path runs on a one-GPU box
  *   --modes a,b,..     rows per size: plain (kernel, then gather in-stream), overlap (own-shard kernel runs while the
  *                      other shards' positions arrive), graph (the {kernel, all-gather} x K chain captured as a
  *                      hipGraph; rccl only).  Default: all the transport allows
@@ -124,7 +128,8 @@ enum { MODE_PLAIN = 0, MODE_OVERLAP = 1, MODE_GRAPH = 2, MODE_COUNT = 3 };
 static const char *const MODE_NAME[MODE_COUNT] = {"plain", "overlap", "graph"};
 
 typedef struct Options {
-    bool use_cpu, use_gpu, own_rng, transport_shm, force_sharded, selftest_ranks, verify_given;
+    bool use_cpu, use_gpu, own_rng, transport_shm, transport_ipc, force_sharded, selftest_ranks, verify_given;
+    /* transport_shm: any host-callback transport (shm or ipc: both need the page's exchange area); transport_ipc: the direct one */
     uint32_t sizes[64];
     uint32_t n_sizes, steps, warmup, galaxies, repeats, verify_steps;
     unsigned seed;
@@ -251,6 +256,7 @@ static uint64_t fnv1a(const void *data, size_t bytes) {
 
 static World *make_sharded_world(const Options *o, NbRankPage *pg, const Particle *ps, uint32_t n) {
     const int rank = nb_rank_page_rank(pg), P = nb_rank_page_nranks(pg);
+    if (o->transport_ipc) return CreateWorldShardedDirect(ps, n, rank, P, nb_rank_allgather, pg);
     if (o->transport_shm) return CreateWorldShardedWith(ps, n, rank, P, nb_rank_allgather, pg);
     unsigned char id[NB_HIP_UNIQUE_ID_BYTES];
     memset(id, 0, sizeof id);
@@ -364,7 +370,7 @@ static int run_rank(const Options *o, NbRankPage *pg) {
                 const double rk_sum = nb_rank_reduce(pg, (double)rk, 's');
                 if (rank == 0)
                     fprintf(stderr, "nbody-bench: %d ranks, transport %s; ranks_with_communicator=%d %s=%d..%d user_rank_sum=%d "
-                            "rccl=%d lib=%s first_gather_ms=%.3f; HIP runtime %d\n", P, o->transport_shm ? "shm" : "rccl", (int)owners,
+                            "rccl=%d lib=%s first_gather_ms=%.3f; HIP runtime %d\n", P, o->transport_ipc ? "ipc" : o->transport_shm ? "shm" : "rccl", (int)owners,
                             (int)owners == P ? "ncclCommCount" : "nranks_argument", (int)nr_min, (int)nr_max, (int)rk_sum, ver, lib, first_ms,
                             nb_hip_runtime_version());
                 if (!o->transport_shm && ((int)owners != P || (int)nr_min != P || (int)nr_max != P || (int)rk_sum != P * (P - 1) / 2)) bad = 1;
@@ -543,8 +549,8 @@ int main(int argc, char **argv) {
             o.own_rng = true;
         } else if (!strcmp(arg, "--gpus") && val) {
             o.gpus = atoi(val), a++;
-        } else if (!strcmp(arg, "--transport") && val && (!strcmp(val, "rccl") || !strcmp(val, "shm"))) {
-            o.transport_shm = !strcmp(val, "shm"), a++;
+        } else if (!strcmp(arg, "--transport") && val && (!strcmp(val, "rccl") || !strcmp(val, "shm") || !strcmp(val, "ipc"))) {
+            o.transport_ipc = !strcmp(val, "ipc"), o.transport_shm = strcmp(val, "rccl") != 0, a++;
         } else if (!strcmp(arg, "--modes") && val) {
             modes = val, a++;
         } else if (!strcmp(arg, "--verify") && val) {
@@ -561,7 +567,7 @@ int main(int argc, char **argv) {
             fprintf(stderr,
                     "usage: %s [--cpu|--gpu] [--n N]... [--steps K] [--warmup W] [--dt DT] [--galaxies G] [--seed S]"
                     " [--own-rng] [--repeats R] [--floor-rate INT_PER_S]\n"
-                    "       [--gpus P [--transport rccl|shm] [--modes plain,overlap,graph] [--verify K] [--force-sharded]"
+                    "       [--gpus P [--transport rccl|ipc|shm] [--modes plain,overlap,graph] [--verify K] [--force-sharded]"
                     " [--wait-timeout S] [--selftest-ranks]]\n",
                     argv[0]);
             return 2;
@@ -584,7 +590,7 @@ int main(int argc, char **argv) {
     if (o.transport_shm)
         for (int i = 0; i < o.n_modes; i++)
             if (o.modes[i] == MODE_GRAPH) {
-                fprintf(stderr, "nbody-bench: mode graph needs --transport rccl (a host callback cannot run inside a captured graph)\n");
+                fprintf(stderr, "nbody-bench: mode graph needs --transport rccl (a host callback or barrier cannot run inside a captured graph)\n");
                 return 2;
             }
     if (o.gpus > 1 || o.force_sharded || o.selftest_ranks) return run_ranks(&o);

@@ -42,6 +42,20 @@ void release_device(SimPipeline *s) {
     use_device();
     ASSERT_HIP(hipStreamSynchronize(s->stream), "sync before release");
     if (s->comm_stream) ASSERT_HIP(hipStreamSynchronize(s->comm_stream), "sync before release");
+    if (s->direct) {
+        // every rank has finished writing into its peers before anyone unmaps or frees (DestroySimPipeline is collective
+        // for direct pipelines); then the mappings go, then -- below -- the memory they pointed at
+        uint64_t tag[64] = {0};
+        tag[s->rank < 64 ? s->rank : 0] = ~0ull;
+        s->host_gather(s->host_gather_ctx, tag, sizeof(uint64_t), s->rank, s->nranks);
+        for (int b = 0; b < 2; b++) {
+            for (int q = 0; q < (int)s->peer_src[b].size(); q++)
+                if (q != s->rank && s->peer_src[b][q]) ASSERT_HIP(hipIpcCloseMemHandle(s->peer_src[b][q]), "hipIpcCloseMemHandle(rank %d)", q);
+            s->peer_src[b].clear();
+        }
+        tag[s->rank < 64 ? s->rank : 0] = ~1ull;
+        s->host_gather(s->host_gather_ctx, tag, sizeof(uint64_t), s->rank, s->nranks);
+    }
     s->pool.destroy();
     s->kernel_iv.clear();
     s->comm_iv.clear();
@@ -125,6 +139,30 @@ void materialize(SimPipeline *s) {
             s->stage_bytes = a > b ? a : b;
             ASSERT_HIP(hipHostMalloc(&s->stage, s->stage_bytes ? s->stage_bytes : 1, hipHostMallocDefault), "staging of %zu bytes",
                        s->stage_bytes);
+        }
+        if (s->direct) {
+            // every rank publishes IPC handles of its two gathered arrays and maps everybody else's
+            NB_ASSERT(s->nranks <= 64, "direct transport: at most 64 ranks");
+            struct Handles {
+                hipIpcMemHandle_t h[2];
+            };
+            std::vector<Handles> all((size_t)s->nranks);
+            for (int b = 0; b < 2; b++)
+                ASSERT_HIP(hipIpcGetMemHandle(&all[(size_t)s->rank].h[b], s->src_pos[b]), "hipIpcGetMemHandle of the gathered array %d", b);
+            s->host_gather(s->host_gather_ctx, all.data(), sizeof(Handles), s->rank, s->nranks);
+            for (int b = 0; b < 2; b++) {
+                s->peer_src[b].assign((size_t)s->nranks, nullptr);
+                for (int q = 0; q < s->nranks; q++) {
+                    if (q == s->rank) {
+                        s->peer_src[b][(size_t)q] = s->src_pos[b];
+                        continue;
+                    }
+                    void *mapped = nullptr;
+                    ASSERT_HIP(hipIpcOpenMemHandle(&mapped, all[(size_t)q].h[b], hipIpcMemLazyEnablePeerAccess),
+                               "hipIpcOpenMemHandle of rank %d's gathered array %d", q, b);
+                    s->peer_src[b][(size_t)q] = static_cast<float2 *>(mapped);
+                }
+            }
         }
     }
     s->on_device = true;
@@ -219,6 +257,12 @@ SimPipeline *CreateSimPipelineShardedWith(WorldData data, int rank, int nranks, 
     s->host_gather_ctx = ctx;
     const char *ov = getenv("NB_HIP_OVERLAP");
     if (ov) s->overlap = atoi(ov) ? 1 : 0;
+    return s;
+}
+
+SimPipeline *CreateSimPipelineShardedDirect(WorldData data, int rank, int nranks, NbAllGatherFn control, void *ctx) {
+    SimPipeline *s = CreateSimPipelineShardedWith(data, rank, nranks, control, ctx);
+    s->direct = true;
     return s;
 }
 

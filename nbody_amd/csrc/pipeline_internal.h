@@ -164,6 +164,13 @@ struct SimPipeline {
     void *host_gather_ctx = nullptr;
     void *stage = nullptr;        // page-locked staging, max(gathered sources, gathered particle slices) bytes
     size_t stage_bytes = 0;
+    // direct transport (CreateSimPipelineShardedDirect): the per-step exchange is P - 1 device-to-device copies of this
+    // rank's slice straight into every peer's gathered array (mapped with hipIpcOpenMemHandle: over xGMI each copy rides
+    // its own link), then a host-side step barrier through the caller's callback.  peer_src[b][q] = rank q's src_pos[b]
+    // as seen from this process (own entry = the local array).
+    bool direct = false;
+    std::vector<float2 *> peer_src[2];
+    uint64_t direct_steps = 0;    // exchanges done: the ranks compare it at every barrier
 
     bool on_device = false;  // buffers exist and hold data
     uint32_t slots = 0;      // receiver slots on this device (allocation; includes a shard's pad slots)

@@ -240,7 +240,7 @@ int nb_hip_comm_info(const SimPipeline *s, int *nranks, int *rank, int *device, 
     if (device) *device = nbi::g_dev.ordinal;
     if (rccl_version) *rccl_version = 0;
     if (first_gather_ms) *first_gather_ms = s->first_gather_ms;
-    if (lib_path && len) snprintf(lib_path, len, "%s", s->host_gather ? "caller-supplied host all-gather" : s->group ? "local group" : "");
+    if (lib_path && len) snprintf(lib_path, len, "%s", s->direct ? "direct device-to-device pushes (IPC-mapped peers) + host step barrier" : s->host_gather ? "caller-supplied host all-gather" : s->group ? "local group" : "");
     if (s->comm == nullptr) return 0;  // unsharded, a local-group member or a caller-supplied transport: no communicator
     // everything below is what the COMMUNICATOR says, not what the caller passed at creation
     if (nranks) ASSERT_NCCL(rccl().CommCount(s->comm, nranks), "ncclCommCount");

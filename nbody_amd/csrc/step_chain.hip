@@ -408,6 +408,26 @@ void allgather_sources(SimPipeline *s, int buf, hipStream_t st) {
         }
         return;
     }
+    if (s->direct) {
+        // the direct all-gather: this rank's slice goes straight into every peer's gathered array, device to device --
+        // over xGMI one copy per peer, each on its own link (no ring, no staging) -- then one host-side barrier: when it
+        // opens, every slice of this array has landed everywhere (each rank synchronised its stream before entering it).
+        // The ping-pong makes the writes safe: peers write into src_pos[buf] while every rank still reads src_pos[buf ^ 1].
+        const size_t off = (size_t)s->rank * per_rank, bytes = per_rank * sizeof(float);
+        for (int q = 0; q < s->nranks; q++) {
+            if (q == s->rank) continue;
+            float *dst = reinterpret_cast<float *>(s->peer_src[buf][(size_t)q]);
+            ASSERT_HIP(hipMemcpyAsync(dst + off, base + off, bytes, hipMemcpyDeviceToDevice, st), "direct push of rank %d's sources to rank %d", s->rank, q);
+        }
+        ASSERT_HIP(hipStreamSynchronize(st), "sync before the step barrier of the direct exchange");
+        uint64_t seen[64];
+        seen[s->rank] = ++s->direct_steps;
+        s->host_gather(s->host_gather_ctx, seen, sizeof(uint64_t), s->rank, s->nranks);
+        for (int q = 0; q < s->nranks; q++)
+            NB_ASSERT(seen[q] == s->direct_steps, "direct exchange: rank %d is at step %llu, rank %d at %llu", q, (unsigned long long)seen[q], s->rank,
+                      (unsigned long long)s->direct_steps);
+        return;
+    }
     if (s->host_gather) {
         host_allgather(s, base, per_rank * sizeof(float), st);
         return;

@@ -58,7 +58,7 @@ static uint32_t partition_by_mass(Particle *p, uint32_t count) {
 
 /* rank < 0: an ordinary single-GPU World; otherwise the sharded pipeline of include/nbody_hip.h. */
 static World *create_world(const Particle *ps, uint32_t size, int rank, int nranks, const void *unique_id128,
-                           NbAllGatherFn allgather, void *ctx) {
+                           NbAllGatherFn allgather, void *ctx, bool direct) {
     World *w = NB_NEW(1, World);
     NB_CHECK(w != NULL, "Failed to alloc World");
     w->particles = NB_NEW(size ? size : 1, Particle);
@@ -69,6 +69,7 @@ static World *create_world(const Particle *ps, uint32_t size, int rank, int nran
     w->massive = partition_by_mass(w->particles, size);
     const WorldData data = {.total_len = size, .mass_len = w->massive, .dt = 0.0f};
     w->gpu = rank < 0     ? CreateSimPipeline(data)
+             : direct    ? CreateSimPipelineShardedDirect(data, rank, nranks, allgather, ctx)
              : allgather ? CreateSimPipelineShardedWith(data, rank, nranks, allgather, ctx)
                          : CreateSimPipelineSharded(data, rank, nranks, unique_id128);
     /* this array is what every later Set/GetSimulationData moves: let the pipeline page-lock it when (if) it
@@ -80,7 +81,7 @@ static World *create_world(const Particle *ps, uint32_t size, int rank, int nran
     return w;
 }
 
-World *CreateWorld(const Particle *ps, uint32_t size) { return create_world(ps, size, -1, 1, NULL, NULL, NULL); }
+World *CreateWorld(const Particle *ps, uint32_t size) { return create_world(ps, size, -1, 1, NULL, NULL, NULL, false); }
 
 /*
  * Extension: one World per process and GPU.  The partition is deterministic, so every rank derives the same
@@ -89,14 +90,21 @@ World *CreateWorld(const Particle *ps, uint32_t size) { return create_world(ps, 
  */
 World *CreateWorldSharded(const Particle *ps, uint32_t size, int rank, int nranks, const void *unique_id128) {
     NB_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "rank %d of %d", rank, nranks);
-    return create_world(ps, size, rank, nranks, unique_id128, NULL, NULL);
+    return create_world(ps, size, rank, nranks, unique_id128, NULL, NULL, false);
 }
 
 /* Extension: the same over a caller-supplied host all-gather (several ranks on ONE GPU, machines without RCCL). */
 World *CreateWorldShardedWith(const Particle *ps, uint32_t size, int rank, int nranks, NbAllGatherFn allgather, void *ctx) {
     NB_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "rank %d of %d", rank, nranks);
     NB_CHECK(allgather != NULL, "NULL all-gather callback");
-    return create_world(ps, size, rank, nranks, NULL, allgather, ctx);
+    return create_world(ps, size, rank, nranks, NULL, allgather, ctx, false);
+}
+
+/* Extension: the same with the direct device-to-device exchange; `control` carries handles and barriers only. */
+World *CreateWorldShardedDirect(const Particle *ps, uint32_t size, int rank, int nranks, NbAllGatherFn control, void *ctx) {
+    NB_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, "rank %d of %d", rank, nranks);
+    NB_CHECK(control != NULL, "NULL control callback");
+    return create_world(ps, size, rank, nranks, NULL, control, ctx, true);
 }
 
 SimPipeline *GetWorldPipeline(World *w) { return w ? w->gpu : NULL; }

@@ -44,6 +44,7 @@ def test_nbody_library_exports_public_surface():
                           "MakeGalaxiesSeeded",                # extension: libc-independent draws
                           "CreateWorldSharded",                # extension: one World per process and GPU
                           "CreateWorldShardedWith",            # ... over a caller-supplied host all-gather
+                          "CreateWorldShardedDirect",          # ... over direct device-to-device pushes (IPC-mapped peers)
                           "GetWorldPipeline"}                  # extension: the pipeline behind a World (knobs, timers)
     have = exported(nb.NBODY_SO)
     assert not [n for n in names if n not in have]

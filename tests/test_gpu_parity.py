@@ -1483,14 +1483,18 @@ def _bench_ranks(args, env=None, timeout=600):
     return subprocess.run([exe] + args, env=e, capture_output=True, text=True, timeout=timeout)
 
 
+@pytest.mark.parametrize("transport", ["shm", "ipc"])
 @pytest.mark.parametrize("P,n", [(2, 4000), (3, 1200), (3, 20000)])
-def test_nbody_bench_c_ranks_on_one_gpu_bitwise(P, n):
-    """nbody-bench --gpus P --transport shm: P REAL processes forked by the C harness before anything touched HIP, each
-    with its own HIP context on this one GPU, one World stepped through CreateWorldShardedWith over the shared page --
-    no Python, no torch, /opt/rocm's HIP runtime.  With one wave per workgroup (NB_HIP_W=1, NB_HIP_K=1) the summation
-    order does not depend on the launch geometry: the in-stream (plain) step must equal the single-GPU World bit for bit."""
+def test_nbody_bench_c_ranks_on_one_gpu_bitwise(P, n, transport):
+    """nbody-bench --gpus P --transport shm | ipc: P REAL processes forked by the C harness before anything touched HIP,
+    each with its own HIP context on this one GPU, one World stepped through CreateWorldShardedWith over the shared page
+    (shm: data staged through the host) or CreateWorldShardedDirect (ipc: every rank maps its peers' source arrays with
+    hipIpcOpenMemHandle and pushes its slice into them device to device; the page carries handles and one barrier per
+    step) -- no Python, no torch, /opt/rocm's HIP runtime.  With one wave per workgroup (NB_HIP_W=1, NB_HIP_K=1) the
+    summation order does not depend on the launch geometry: the in-stream (plain) step must equal the single-GPU World
+    bit for bit."""
     import re
-    r = _bench_ranks(["--gpus", str(P), "--transport", "shm", "--n", str(n), "--steps", "6", "--warmup", "2", "--dt", "0.01",
+    r = _bench_ranks(["--gpus", str(P), "--transport", transport, "--n", str(n), "--steps", "6", "--warmup", "2", "--dt", "0.01",
                       "--modes", "plain", "--verify", "4"], env={"NB_HIP_W": "1", "NB_HIP_K": "1"})
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     v = re.findall(r"verify N=(\d+) mode=(\w+) steps=4: ranks agree (\w+); vs single GPU: rel_l2_pos ([0-9.e+-]+) max_abs_pos ([0-9.e+-]+) bitwise (\w+)", r.stderr)
@@ -1498,15 +1502,17 @@ def test_nbody_bench_c_ranks_on_one_gpu_bitwise(P, n):
     rows = [l.split() for l in r.stdout.strip().splitlines()]
     assert rows[0][:4] == ["N", "ranks", "mode", "GPU"] and rows[1][:3] == [str(n), str(P), "plain"]
     assert float(rows[1][3]) > 0 and float(rows[1][-2]) > 0 and float(rows[1][-1]) > 0     # us/step, kernel ms, gather ms
-    assert f"{P} ranks, transport shm; ranks_with_communicator=0" in r.stderr
+    assert f"{P} ranks, transport {transport}; ranks_with_communicator=0" in r.stderr
+    assert ("direct device-to-device pushes" in r.stderr) == (transport == "ipc")
 
 
-def test_nbody_bench_c_ranks_default_shapes_and_overlap():
+@pytest.mark.parametrize("transport", ["shm", "ipc"])
+def test_nbody_bench_c_ranks_default_shapes_and_overlap(transport):
     """The same with the library's own launch shapes, both step modes, two sizes in one run (the second World gets a
     fresh exchange): every rank holds the same bytes and they stay within 1e-5 relative L2 of the single-GPU positions
     (the harness' own bound; observed ~1e-8)."""
     import re
-    r = _bench_ranks(["--gpus", "2", "--transport", "shm", "--n", "4096", "--n", "65536", "--steps", "5", "--warmup", "1", "--dt", "0.01"])
+    r = _bench_ranks(["--gpus", "2", "--transport", transport, "--n", "4096", "--n", "65536", "--steps", "5", "--warmup", "1", "--dt", "0.01"])
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     v = re.findall(r"verify N=(\d+) mode=(\w+) steps=3: ranks agree (\w+); vs single GPU: rel_l2_pos ([0-9.e+-]+)", r.stderr)
     assert [(a, b, c) for a, b, c, _ in v] == [("4096", "plain", "yes"), ("4096", "overlap", "yes"), ("65536", "plain", "yes"),
