@@ -382,10 +382,11 @@ def main():
                     help="particles (default 2^20, the size the metric is quoted on); not --n: torchrun claims that prefix")
     ap.add_argument("--extra-particles", dest="n5", type=int, default=N_CONFIG5,
                     help="size of the second sharded workload under extra_configs (default 2^22 = BASELINE.json config 5)")
-    ap.add_argument("--transport", choices=("rccl", "host"), default="rccl",
-                    help="N > 1: rccl = in-stream ncclAllGather (the product path); host = the library's caller-supplied "
-                         "transport over the rendezvous link (host-staged, slow): lets several ranks share ONE GPU to "
-                         "rehearse the multi-process flow where RCCL refuses duplicate devices")
+    ap.add_argument("--transport", choices=("rccl", "host", "direct"), default="rccl",
+                    help="N > 1: rccl = in-stream ncclAllGather (the product path); direct = no RCCL: every rank pushes its slice "
+                         "device-to-device into its peers' IPC-mapped source arrays, one barrier per step over the rendezvous link "
+                         "(the fallback should RCCL not come up); host = data staged through the host over the rendezvous link "
+                         "(slow).  direct and host let several ranks share ONE GPU, where RCCL refuses duplicate devices")
     ap.add_argument("--rendezvous", choices=("socket", "gloo"), default="socket",
                     help="N > 1: how the ranks meet on the host.  socket = a stdlib Unix-socket hub (no torch import: the run "
                          "binds /opt/rocm's HIP runtime and librccl); gloo = torch.distributed (torch's bundled runtime loads first)")
@@ -495,7 +496,7 @@ def main():
 
     current_leg = {"name": "headline"}
     gloo_gather = None
-    if args.transport == "host" and sharded:
+    if args.transport in ("host", "direct") and sharded:
         def gloo_gather(rows, r, n):
             """In-place all-gather of host rows over the rendezvous (rows[r] is filled on entry)."""
             if args.stall_leg and current_leg["name"] == args.stall_leg:
@@ -520,7 +521,7 @@ def main():
         if not sharded:
             return nb.SimPipeline(n_, m_)
         if gloo_gather is not None:
-            return nb.SimPipeline(n_, m_, rank=rank, nranks=world, allgather=gloo_gather)
+            return nb.SimPipeline(n_, m_, rank=rank, nranks=world, allgather=gloo_gather, direct=args.transport == "direct")
         return nb.SimPipeline(n_, m_, rank=rank, nranks=world, unique_id=new_unique_id())
 
     if not args.dry_run:
@@ -678,7 +679,8 @@ def main():
                                 f", partitioned; N={n}, mass_len={mass_len}, "
                                 f"dt={DT}; {n * mass_len:.4g} interactions/step; one PerformSimUpdate({args.steps}) call",
                     "parallelism": (f"receivers sharded N/{world} per GPU, all-gather of source positions per step"
-                                    + (" over the caller-supplied HOST transport (rehearsal, not RCCL)" if gloo_gather else ""))
+                                    + (" by direct device-to-device pushes (no RCCL)" if args.transport == "direct" else
+                                       " over the caller-supplied HOST transport (rehearsal, not RCCL)" if gloo_gather else ""))
                                    if world > 1 else "single GPU",
                     "kernel": shape,
                     "device": info,
@@ -690,7 +692,9 @@ def main():
                 # ncclCommCount as seen by every rank's communicator -- null when a rank holds none (host transport, dry run)
                 out["rccl_nranks"] = (extras["rccl"]["nranks_reported"]["min"]
                                       if extras["rccl"]["ranks_with_communicator"] == world else None)
-                out["transport"] = ("host (all-gather over the rendezvous link through page-locked staging)" if gloo_gather
+                out["transport"] = ("direct (device-to-device pushes into IPC-mapped peers, one barrier per step over the rendezvous link)"
+                                    if args.transport == "direct" else
+                                    "host (all-gather over the rendezvous link through page-locked staging)" if gloo_gather
                                     else "rccl (in-stream ncclAllGather)")
             out.update(extras)
             if cpu is not None:

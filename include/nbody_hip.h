@@ -269,7 +269,8 @@ SimPipeline *CreateSimPipelineShardedWith(WorldData data, int rank, int nranks, 
  * the P - 1 copies rides its own link: the direct all-gather, where a ring would serialise P - 1 hops per link -- then
  * synchronises its stream and meets the other ranks in ONE host-side barrier per step (an 8-byte all-gather of step
  * counters through `control`; every rank must be at the same step or the call aborts).  `control` is the same in-place
- * host all-gather callback as above; it carries the IPC handles at the first SetSimulationData, the per-step barrier, the
+ * host all-gather callback as above; it carries the IPC handles at the first SetSimulationData, a barrier at the end of
+ * every SetSimulationData (no peer may push into arrays their owner is still initialising), the per-step barrier, the
  * particle slices of a collective GetSimulationData, and one barrier in DestroySimPipeline (which is therefore a
  * collective for these pipelines: nobody unmaps or frees while a peer may still write).  Costs a host round trip per
  * step like the host transport (no hipGraph capture, no overlap gain) but moves no particle data through the host:

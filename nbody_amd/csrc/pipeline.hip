@@ -386,6 +386,13 @@ void set_simulation_data(SimPipeline *s, const Particle *ps) {
         if (s->overlap) ASSERT_HIP(hipEventRecord(s->ev_gather, s->group ? s->stream : s->comm_stream), "prime gather event");
     }
     ASSERT_HIP(hipStreamSynchronize(st), "sync after SetSimulationData");
+    if (s->direct) {
+        // nobody may push a step's slice into a peer's gathered arrays before that peer has finished initialising them
+        // (its split_sources launch above rewrites both arrays whole): one barrier, after which every rank's upload is done
+        uint64_t ready[64] = {0};
+        ready[s->rank] = 1;
+        s->host_gather(s->host_gather_ctx, ready, sizeof(uint64_t), s->rank, s->nranks);
+    }
     // small worlds in auto mode: have the canonical chain ready before the first step call (see wants_canonical)
     if (wants_canonical(s)) (void)find_or_build_graph(s, CANON_STEPS, 0.0f, resolve_shape(s));
 }

@@ -1632,20 +1632,22 @@ def test_sharded_pipeline_with_real_processes_on_one_gpu(golden, tmp_path, world
     assert np.array_equal(got[1][:, 6:8], want[:, 6:8])
 
 
-def test_bench_with_two_real_ranks_on_one_gpu():
+@pytest.mark.parametrize("transport", ["host", "direct"])
+def test_bench_with_two_real_ranks_on_one_gpu(transport):
     """bench.py as the driver launches it for N = 2 -- two processes, barriers, reductions over the ranks, self-check
-    against the single-GPU pipeline, extra_configs -- with both ranks on this one GPU over the host transport."""
+    against the single-GPU pipeline, extra_configs -- with both ranks on this one GPU over the host transport, and over
+    the direct one (slices pushed device-to-device into IPC-mapped peers, one barrier per step over the socket hub)."""
     import json
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29741", os.path.join(nb.ROOT, "bench.py"), "--gpus", "2", "--transport", "host",
-           "--steps", "4", "--warmup", "1", "--particles", "65536", "--extra-particles", "131072"]
+           "--master-port", "29741" if transport == "host" else "29742", os.path.join(nb.ROOT, "bench.py"), "--gpus", "2",
+           "--transport", transport, "--steps", "4", "--warmup", "1", "--particles", "65536", "--extra-particles", "131072"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=nb.ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = r.stdout.splitlines()
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]      # stdout carries the JSON line only
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["value"] > 1e10 and out["rccl_nranks"] is None and out["transport"].startswith("host")
+    assert out["n_gpus"] == 2 and out["value"] > 1e10 and out["rccl_nranks"] is None and out["transport"].startswith(transport)
     assert out["rccl"]["user_ranks"] == {"min": 0, "max": 1, "sum": 1} and out["rccl"]["ranks_with_communicator"] == 0
     check = out["self_check"]
     assert check["ranks_agree"] is True and check["static_fields_equal"] is True and check["steps"] == 5

@@ -37,6 +37,9 @@ done
     echo
     echo "== nbody-bench --gpus $P --transport shm --n 4096 --n 65536 --n 1048576 --steps 10 --warmup 2 --dt 0.01: $P real C processes on ONE MI355X (host-staged exchange over the shared page; all ranks share the GPU, so the rate is one GPU's) =="
     ./nbody_amd/lib/nbody-bench --gpus $P --transport shm --n 4096 --n 65536 --n 1048576 --steps 10 --warmup 2 --dt 0.01
+    echo
+    echo "== nbody-bench --gpus $P --transport ipc (same sizes): the direct exchange -- every rank pushes its slice device-to-device into its peers' IPC-mapped source arrays, one barrier per step at the page =="
+    ./nbody_amd/lib/nbody-bench --gpus $P --transport ipc --n 4096 --n 65536 --n 1048576 --steps 10 --warmup 2 --dt 0.01
   done
 } > $O/${TAG}_nbody_bench_ranks.txt 2>&1; echo "C ranks rc=$?"
 python tools/gpu_vs_avx.py > $O/${TAG}_gpu_vs_avx.txt 2>&1; echo "gpu-vs-avx rc=$?"
