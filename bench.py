@@ -496,8 +496,9 @@ def main():
 
     current_leg = {"name": "headline"}
     gloo_gather = None
-    if args.transport in ("host", "direct") and sharded:
-        def gloo_gather(rows, r, n):
+    link_gather = None
+    if sharded:
+        def link_gather(rows, r, n):
             """In-place all-gather of host rows over the rendezvous (rows[r] is filled on entry)."""
             if args.stall_leg and current_leg["name"] == args.stall_leg:
                 time.sleep(3600.0)   # rehearsal of a collective that never completes (--stall-leg)
@@ -516,6 +517,9 @@ def main():
             for q in range(n):
                 if q != r:
                     rows[q] = parts[q].numpy()
+
+    if args.transport in ("host", "direct") and sharded:
+        gloo_gather = link_gather
 
     def make_sim(n_, m_):
         if not sharded:
@@ -730,7 +734,8 @@ def main():
                 _extra_entry(n, mass_len, 0, 1, args.steps, 0.0, None, world),
                 _extra_entry(part5.shape[0], m5, 0, 0, 3, 0.0, None, world),
                 _extra_entry(part5.shape[0], m5, 1, 0, 3, 0.0, None, world),
-            ])
+            ] + ([dict(_extra_entry(n, mass_len, 0, 0, args.steps, 0.0, None, world), transport="direct (dry run)")]
+                 if gloo_gather is None else []))
         else:
             # every rank must hold the same full state, and it must be the single-GPU state of the same steps
             leg("self_check")
@@ -785,6 +790,18 @@ def main():
                 e5 = timed_leg(sim5, 3, 1)
                 extra.append(_extra_entry(part5.shape[0], m5, ov, 0, 3, e5, sharded_detail(sim5, 3), world))
             sim5.close()
+            # last and least travelled: the direct exchange (no RCCL; slices pushed device-to-device into IPC-mapped peers,
+            # one barrier per step over the rendezvous link) on the headline workload, for an RCCL-vs-direct comparison
+            # from the same command -- only when the run's own transport is RCCL (otherwise the legs above were it)
+            if gloo_gather is None and link_gather is not None:
+                leg("direct")
+                simd = nb.SimPipeline(n, mass_len, rank=rank, nranks=world, allgather=link_gather, direct=True)
+                simd.set_data(part)
+                ed = timed_leg(simd, args.steps, 1)
+                entry = _extra_entry(n, mass_len, 0, 0, args.steps, ed, sharded_detail(simd, args.steps), world)
+                entry["transport"] = "direct (device-to-device pushes into IPC-mapped peers, one host barrier per step)"
+                extra.append(entry)
+                simd.close()
             if guard:
                 guard.disarm()
             if gasp:

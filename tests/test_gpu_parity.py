@@ -1302,7 +1302,8 @@ def test_bench_under_torchrun_with_one_forced_sharded_rank(mode, rendezvous):
         assert out["comm_ms_per_step"]["max"] > 0 and out["kernel_ms_per_step"]["max"] > 0
     extra = out["extra_configs"]
     # overlapped step; the {kernel, ncclAllGather} x K chain captured as a hipGraph and replayed (north star); config 5 x 2
-    assert [(e["overlap"], e["sharded_graph"]) for e in extra] == [(1, 0), (0, 1), (0, 0), (1, 0)]
+    assert [(e["overlap"], e["sharded_graph"]) for e in extra] == [(1, 0), (0, 1), (0, 0), (1, 0), (0, 0)]
+    assert extra[4]["transport"].startswith("direct")    # last leg: the RCCL-free direct exchange on the headline workload
     assert all(e["value"] > 1e11 for e in extra) and "extras_aborted" not in out
     assert extra[1]["graph_stats"]["cached"] >= 1        # RCCL inside stream capture, instantiated and replayed
     assert all(e["comm_ms_per_step"]["max"] > 0 for e in extra if not e["sharded_graph"] and (e["overlap"] == 1 or mode == "plain"))

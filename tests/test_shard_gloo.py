@@ -58,8 +58,9 @@ def test_bench_multi_rank_control_flow_dry_run(world, rendezvous):
     extra = out["extra_configs"]
     # overlapped step, the chain captured as a hipGraph (north star), then config 5 plain and overlapped
     assert [(e["overlap"], e["sharded_graph"], "N=65536" in e["workload"]) for e in extra] == \
-        [(1, 0, True), (0, 1, True), (0, 0, False), (1, 0, False)]
-    assert all("N=131072" in e["workload"] for e in extra[2:])
+        [(1, 0, True), (0, 1, True), (0, 0, False), (1, 0, False), (0, 0, True)]
+    assert all("N=131072" in e["workload"] for e in extra[2:4])
+    assert extra[4]["transport"].startswith("direct")       # RCCL runs end with the direct exchange on the headline workload
     for e in extra:
         assert set(e) >= {"workload", "overlap", "sharded_graph", "steps", "ms_per_step", "steps_per_sec", "value", "unit",
                           "kernel_ms_per_step", "comm_ms_per_step"}
