@@ -392,6 +392,22 @@ void host_allgather(SimPipeline *s, void *dev_base, size_t bytes_per_rank, hipSt
                    "H2D of the slots after rank %d's", s->rank);
 }
 
+// The direct exchange's data movement: ONE launch reads this rank's slice once and stores it into every peer's gathered
+// array (IPC-mapped; over xGMI each peer's stores ride that peer's own link), instead of P - 1 separately submitted
+// copies.  16-byte accesses; the slice length is a multiple of 64 float2.
+constexpr int DIRECT_PUSH_MAX_PEERS = 15;
+struct PushTargets {
+    float4 *dst[DIRECT_PUSH_MAX_PEERS];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void direct_push_kernel(const float4 *__restrict__ src, PushTargets to, uint32_t count4) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count4) return;
+    const float4 v = src[i];
+    for (int q = 0; q < to.n; q++) to.dst[q][i] = v;
+}
+
 void allgather_sources(SimPipeline *s, int buf, hipStream_t st) {
     // in place: this rank's slice already sits at rank * Mc (written by the step kernel's mirror store)
     const size_t per_rank = (size_t)s->plan.mass_chunk * 2;  // floats
@@ -414,10 +430,20 @@ void allgather_sources(SimPipeline *s, int buf, hipStream_t st) {
         // opens, every slice of this array has landed everywhere (each rank synchronised its stream before entering it).
         // The ping-pong makes the writes safe: peers write into src_pos[buf] while every rank still reads src_pos[buf ^ 1].
         const size_t off = (size_t)s->rank * per_rank, bytes = per_rank * sizeof(float);
-        for (int q = 0; q < s->nranks; q++) {
-            if (q == s->rank) continue;
-            float *dst = reinterpret_cast<float *>(s->peer_src[buf][(size_t)q]);
-            ASSERT_HIP(hipMemcpyAsync(dst + off, base + off, bytes, hipMemcpyDeviceToDevice, st), "direct push of rank %d's sources to rank %d", s->rank, q);
+        if (s->nranks - 1 <= DIRECT_PUSH_MAX_PEERS && s->nranks > 1) {
+            PushTargets to;
+            to.n = 0;
+            for (int q = 0; q < s->nranks; q++)
+                if (q != s->rank) to.dst[to.n++] = reinterpret_cast<float4 *>(reinterpret_cast<float *>(s->peer_src[buf][(size_t)q]) + off);
+            const uint32_t count4 = (uint32_t)(per_rank / 4);   // per_rank floats = Mc float2, Mc a multiple of 64
+            hipLaunchKernelGGL(direct_push_kernel, dim3((count4 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float4 *>(base + off), to, count4);
+            ASSERT_HIP(hipGetLastError(), "direct push launch (rank %d, %d peers)", s->rank, to.n);
+        } else {
+            for (int q = 0; q < s->nranks; q++) {
+                if (q == s->rank) continue;
+                float *dst = reinterpret_cast<float *>(s->peer_src[buf][(size_t)q]);
+                ASSERT_HIP(hipMemcpyAsync(dst + off, base + off, bytes, hipMemcpyDeviceToDevice, st), "direct push of rank %d's sources to rank %d", s->rank, q);
+            }
         }
         ASSERT_HIP(hipStreamSynchronize(st), "sync before the step barrier of the direct exchange");
         uint64_t seen[64];
