@@ -55,6 +55,7 @@
  * the stragglers (exact pids) and reports -- it never re-executes anything.
  */
 #define _GNU_SOURCE
+#include <errno.h>
 #include <signal.h>
 #include <stdbool.h>
 #include <stdio.h>
@@ -480,6 +481,7 @@ static int run_ranks(const Options *o) {
             }
             continue;
         }
+        if (pid < 0 && errno == ECHILD) break; /* nothing left to wait for */
         struct timespec ts = {0, 20 * 1000 * 1000};
         nanosleep(&ts, NULL);
         if (failed_at > 0.0 && seconds_now() - failed_at > 15.0) {

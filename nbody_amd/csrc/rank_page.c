@@ -99,7 +99,9 @@ static void wait_until(NbRankPage *pg, atomic_uint *var, unsigned not_equal_to, 
         if (atomic_load_explicit(&pg->sh->failed, memory_order_relaxed)) leave(pg, "another rank failed", what);
         spins++;
         if (spins < 4096) {
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#endif
         } else if (spins < 8192) {
             sched_yield();
         } else {
