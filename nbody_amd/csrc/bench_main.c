@@ -46,6 +46,8 @@
  *                      (default 3; 0 = skip).  A deviation above 1e-5 relative L2 in positions fails the run.
  *                      Without --gpus (and with both backends): K steps of UpdateWorld_GPU against K steps of
  *                      UpdateWorld_CPU per row, relative to what the steps moved; above 1e-4 the run fails
+ *   --speedup          rank 0 also times the same K steps on an ordinary single-GPU World (its own device, the other ranks
+ *                      wait) and the table gains "1-GPU us" and "speedup" columns: strong scaling from one command
  *   --force-sharded    with --gpus 1: still go through the RCCL path (one-rank communicator)
  *   --wait-timeout S   how long a rank waits for the others at the page before it gives up (default 180)
  *   --selftest-ranks   no GPU: P ranks exercise the page only (barriers, id hand-over, reductions, all-gathers)
@@ -129,7 +131,7 @@ enum { MODE_PLAIN = 0, MODE_OVERLAP = 1, MODE_GRAPH = 2, MODE_COUNT = 3 };
 static const char *const MODE_NAME[MODE_COUNT] = {"plain", "overlap", "graph"};
 
 typedef struct Options {
-    bool use_cpu, use_gpu, own_rng, transport_shm, transport_ipc, force_sharded, selftest_ranks, verify_given;
+    bool use_cpu, use_gpu, own_rng, transport_shm, transport_ipc, force_sharded, selftest_ranks, verify_given, speedup;
     /* transport_shm: any host-callback transport (shm or ipc: both need the page's exchange area); transport_ipc: the direct one */
     uint32_t sizes[64];
     uint32_t n_sizes, steps, warmup, galaxies, repeats, verify_steps;
@@ -322,7 +324,8 @@ static int run_rank(const Options *o, NbRankPage *pg) {
     nb_hip_set_device(o->transport_shm ? rank % ndev : rank);
 
     if (rank == 0) {
-        printf("\t      N\t  ranks\t   mode\t     GPU us\t   steps/s\t  GPU int/s\t GPU %%peak\tkernel ms\tgather ms\n");
+        printf("\t      N\t  ranks\t   mode\t     GPU us\t   steps/s\t  GPU int/s\t GPU %%peak\tkernel ms\tgather ms%s\n",
+               o->speedup ? "\t  1-GPU us\t  speedup" : "");
         fflush(stdout);
     }
     int bad = 0;
@@ -337,6 +340,15 @@ static int run_rank(const Options *o, NbRankPage *pg) {
         }
         if (o->verify_steps > 0) bad = verify_row(o, pg, ps, n) || bad;
 
+        double single_s = 0.0; /* --speedup: the same call on one GPU, timed by rank 0 while the others wait at the barrier */
+        if (o->speedup) {
+            if (rank == 0) {
+                World *one = CreateWorld(ps, n);
+                single_s = time_backend(one, UpdateWorld_GPU, o->dt, o->warmup, o->steps, o->repeats);
+                DestroyWorld(one);
+            }
+            nb_rank_barrier(pg, "after the single-GPU reference timing");
+        }
         World *w = make_sharded_world(o, pg, ps, n);
         SimPipeline *sim = GetWorldPipeline(w);
         nb_hip_configure(sim, "timing", 1);
@@ -378,8 +390,10 @@ static int run_rank(const Options *o, NbRankPage *pg) {
             }
             if (rank == 0) {
                 const double per = best / (double)o->steps;
-                printf("\t%7u\t%7d\t%7s\t%11.2f\t%10.2f\t%11.3e\t%9.1f\t%9.4f\t%9.4f\n", n, P, MODE_NAME[mode], per * 1e6, 1.0 / per,
+                printf("\t%7u\t%7d\t%7s\t%11.2f\t%10.2f\t%11.3e\t%9.1f\t%9.4f\t%9.4f", n, P, MODE_NAME[mode], per * 1e6, 1.0 / per,
                        pairs / per, pairs / per * 14.0 / (157.3e12 * P) * 100.0, k_ms, c_ms);
+                if (o->speedup) printf("\t%10.2f\t%9.2f", single_s * 1e6, single_s / per);
+                printf("\n");
                 fflush(stdout);
             }
         }
@@ -561,6 +575,8 @@ int main(int argc, char **argv) {
             o.wait_timeout_s = strtod(val, NULL), a++;
         } else if (!strcmp(arg, "--force-sharded")) {
             o.force_sharded = true;
+        } else if (!strcmp(arg, "--speedup")) {
+            o.speedup = true;
         } else if (!strcmp(arg, "--selftest-ranks")) {
             o.selftest_ranks = true;
         } else if (!strcmp(arg, "--selftest-die") && val) {
@@ -569,7 +585,7 @@ int main(int argc, char **argv) {
             fprintf(stderr,
                     "usage: %s [--cpu|--gpu] [--n N]... [--steps K] [--warmup W] [--dt DT] [--galaxies G] [--seed S]"
                     " [--own-rng] [--repeats R] [--floor-rate INT_PER_S]\n"
-                    "       [--gpus P [--transport rccl|ipc|shm] [--modes plain,overlap,graph] [--verify K] [--force-sharded]"
+                    "       [--gpus P [--transport rccl|ipc|shm] [--modes plain,overlap,graph] [--verify K] [--speedup] [--force-sharded]"
                     " [--wait-timeout S] [--selftest-ranks]]\n",
                     argv[0]);
             return 2;
@@ -595,6 +611,8 @@ int main(int argc, char **argv) {
                 fprintf(stderr, "nbody-bench: mode graph needs --transport rccl (a host callback or barrier cannot run inside a captured graph)\n");
                 return 2;
             }
+    /* the other ranks wait at the page while rank 0 times the single-GPU reference: K steps of the whole world on one GPU */
+    if (o.speedup && o.wait_timeout_s == 180.0) o.wait_timeout_s = 3600.0;
     if (o.gpus > 1 || o.force_sharded || o.selftest_ranks) return run_ranks(&o);
     return run_single(&o);
 }

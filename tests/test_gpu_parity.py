@@ -1522,6 +1522,12 @@ def test_nbody_bench_c_ranks_default_shapes_and_overlap(transport):
     rows = [l.split() for l in r.stdout.strip().splitlines()][1:]
     assert [(x[0], x[2]) for x in rows] == [("4096", "plain"), ("4096", "overlap"), ("65536", "plain"), ("65536", "overlap")]
     assert all(float(x[5]) > 1e9 for x in rows)
+    # --speedup: rank 0 times the same call on a single-GPU World; with every rank on ONE GPU the "speedup" is below 1
+    r = _bench_ranks(["--gpus", "2", "--transport", transport, "--n", "20000", "--steps", "5", "--warmup", "1", "--dt", "0.01",
+                      "--modes", "plain", "--verify", "0", "--speedup"])
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    head, row = [l.split() for l in r.stdout.strip().splitlines()]
+    assert head[-2:] == ["us", "speedup"] and 0.05 < float(row[-1]) < 1.5 and float(row[-2]) > 10
 
 
 def test_nbody_bench_c_one_forced_rccl_rank():
