@@ -495,7 +495,7 @@ def main():
         return _digests_agree(dist, torch, digest)
 
     current_leg = {"name": "headline"}
-    gloo_gather = None
+    host_gather = None
     link_gather = None
     if sharded:
         def link_gather(rows, r, n):
@@ -519,13 +519,13 @@ def main():
                     rows[q] = parts[q].numpy()
 
     if args.transport in ("host", "direct") and sharded:
-        gloo_gather = link_gather
+        host_gather = link_gather
 
     def make_sim(n_, m_):
         if not sharded:
             return nb.SimPipeline(n_, m_)
-        if gloo_gather is not None:
-            return nb.SimPipeline(n_, m_, rank=rank, nranks=world, allgather=gloo_gather, direct=args.transport == "direct")
+        if host_gather is not None:
+            return nb.SimPipeline(n_, m_, rank=rank, nranks=world, allgather=host_gather, direct=args.transport == "direct")
         return nb.SimPipeline(n_, m_, rank=rank, nranks=world, unique_id=new_unique_id())
 
     if not args.dry_run:
@@ -684,7 +684,7 @@ def main():
                                 f"dt={DT}; {n * mass_len:.4g} interactions/step; one PerformSimUpdate({args.steps}) call",
                     "parallelism": (f"receivers sharded N/{world} per GPU, all-gather of source positions per step"
                                     + (" by direct device-to-device pushes (no RCCL)" if args.transport == "direct" else
-                                       " over the caller-supplied HOST transport (rehearsal, not RCCL)" if gloo_gather else ""))
+                                       " over the caller-supplied HOST transport (rehearsal, not RCCL)" if host_gather else ""))
                                    if world > 1 else "single GPU",
                     "kernel": shape,
                     "device": info,
@@ -698,7 +698,7 @@ def main():
                                       if extras["rccl"]["ranks_with_communicator"] == world else None)
                 out["transport"] = ("direct (device-to-device pushes into IPC-mapped peers, one barrier per step over the rendezvous link)"
                                     if args.transport == "direct" else
-                                    "host (all-gather over the rendezvous link through page-locked staging)" if gloo_gather
+                                    "host (all-gather over the rendezvous link through page-locked staging)" if host_gather
                                     else "rccl (in-stream ncclAllGather)")
             out.update(extras)
             if cpu is not None:
@@ -735,7 +735,7 @@ def main():
                 _extra_entry(part5.shape[0], m5, 0, 0, 3, 0.0, None, world),
                 _extra_entry(part5.shape[0], m5, 1, 0, 3, 0.0, None, world),
             ] + ([dict(_extra_entry(n, mass_len, 0, 0, args.steps, 0.0, None, world), transport="direct (dry run)")]
-                 if gloo_gather is None else []))
+                 if host_gather is None else []))
         else:
             # every rank must hold the same full state, and it must be the single-GPU state of the same steps
             leg("self_check")
@@ -765,7 +765,7 @@ def main():
             # from the stream and replayed (RCCL inside stream capture; a host callback cannot be captured)
             leg("sharded_graph")
             sim.configure(overlap=0)
-            if gloo_gather is None:
+            if host_gather is None:
                 sim.configure(sharded_graph=1)
                 eg = timed_leg(sim, args.steps, args.steps)   # the warm-up call captures and instantiates the chain
                 entry = _extra_entry(n, mass_len, 0, 1, args.steps, eg, None, world)
@@ -793,7 +793,7 @@ def main():
             # last and least travelled: the direct exchange (no RCCL; slices pushed device-to-device into IPC-mapped peers,
             # one barrier per step over the rendezvous link) on the headline workload, for an RCCL-vs-direct comparison
             # from the same command -- only when the run's own transport is RCCL (otherwise the legs above were it)
-            if gloo_gather is None and link_gather is not None:
+            if host_gather is None and link_gather is not None:
                 leg("direct")
                 simd = nb.SimPipeline(n, mass_len, rank=rank, nranks=world, allgather=link_gather, direct=True)
                 simd.set_data(part)
