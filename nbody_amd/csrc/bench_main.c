@@ -308,7 +308,7 @@ static int verify_row(const Options *o, NbRankPage *pg, const Particle *ps, uint
         bad = bad || !agree || !(rel <= 1e-5);
     }
     if (one) DestroyWorld(one);
-    DestroyWorld(w); /* collective-free: every rank tears its communicator down on its own */
+    DestroyWorld(w); /* every rank, same place: a collective for the direct exchange (one barrier before anyone unmaps) */
     return nb_rank_reduce(pg, (double)bad, 'x') > 0.0;
 }
 
