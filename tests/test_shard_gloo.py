@@ -28,7 +28,7 @@ def test_sharded_exchange_reproduces_single_rank(tmp_path, golden, world, n):
     assert got.tobytes() == want.tobytes()
 
 
-@pytest.mark.parametrize("world,rendezvous", [(2, "socket"), (3, "socket"), (2, "gloo")])
+@pytest.mark.parametrize("world,rendezvous", [(2, "socket"), (3, "socket"), (8, "socket"), (2, "gloo")])
 def test_bench_multi_rank_control_flow_dry_run(world, rendezvous):
     """bench.py under torch.distributed.run, world_size > 1, no GPU: rendezvous (the stdlib socket hub by default, gloo on
     request), RCCL-id broadcast, barriers, max-over-ranks reduction and the one JSON line on rank 0 (the sharded device
