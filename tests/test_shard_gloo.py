@@ -184,3 +184,32 @@ print("ok", rank)
     outs = [p.communicate(timeout=120) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert sorted(o[0].strip() for o in outs) == [f"ok {r}" for r in range(world)]
+
+
+def test_rank_link_a_dying_rank_ends_the_others_quickly():
+    """A rank that dies mid-run must not leave the others blocked until the 900 s socket timeout: rank 1 exits before the
+    second collective, the hub (rank 0) sees its socket close and raises, rank 2 sees the hub's close and raises."""
+    import time
+    root = os.path.dirname(HERE)
+    code = f"""
+import os, sys
+sys.path.insert(0, {root!r})
+from nbody_amd.ranklink import RankLink
+rank = int(sys.argv[1])
+link = RankLink(rank, 3, name="nbody_test_die_{os.getpid()}", timeout_s=120)
+link.barrier()
+if rank == 1:
+    os._exit(7)
+link.barrier()
+link.barrier()
+print("NOT REACHED")
+"""
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(3)]
+    outs = [p.communicate(timeout=100) for p in procs]
+    assert time.time() - t0 < 30
+    assert procs[1].returncode == 7
+    assert procs[0].returncode != 0 and procs[2].returncode != 0
+    assert all("NOT REACHED" not in o[0] for o in outs)
+    assert "ConnectionError" in outs[0][1] or "Connection" in outs[0][1] or "Broken" in outs[0][1]
