@@ -181,6 +181,13 @@ void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
  *               compute unit is slower than per-step launches over the whole chip) and the launch shape is on auto; 1 =
  *               whenever the world fits; 0 = never.  Same bits as per-step launches with k = 2, w = 16 / tiles, split = 1,
  *               unit = 8 (tiles = 1, 2, 4 for N <= 128, 256, 512); nb_hip_launch_shape reports that shape
+ *   "fused_finish"  split shapes without their second kernel: the workgroup of a receiver tile that arrives LAST adds
+ *               the tile's parts (written and read with agent-scope sc1 accesses, one ticket per tile) and integrates, in
+ *               the same order and with the same roundings as the finish kernel: same bits, one dependent launch less
+ *               per pass.  2 (default) = auto: unsharded steps on the scalar-cache route with N x M >= 4e7 (N >~ 9 000;
+ *               below that it loses inside a hipGraph) and at most 200 000 receivers: -0.4 ... -2.3 us per step at
+ *               N = 10 000 ... 100 000 (profiles/r04_fused_finish.txt); 1 = whenever the shape has a split and the
+ *               route is the scalar cache; 0 = never.  Sharded steps always use the finish kernel
  *   "readback"  when the device state reaches the host array named by nb_hip_note_host_array: 0 = only when
  *               GetSimulationData asks (merge kernel + D2H copy + wait), 1 = at the end of every blocking
  *               PerformSimUpdate (the merge kernel is appended to the update's own submission and stores straight into
@@ -228,6 +235,10 @@ void nb_hip_plan_launch(uint32_t n_recv, uint32_t n_src, int compute_units, int 
  * waves per workgroup.  Lane-split steps are ONE kernel (no finish kernel).
  */
 int nb_hip_plan_launch_lanes(uint32_t n_recv, uint32_t n_src, int *w);
+
+/* 1 when an unsharded all-auto step of that size runs its source split WITHOUT the finish kernel ("fused_finish" knob on
+ * auto): one kernel per pass instead of two.  Pure host code. */
+int nb_hip_plan_fused_finish(uint32_t n_recv, uint32_t n_src, int compute_units);
 
 /* The source-slice granule ("unit" knob: 64, 32, 16 or 8 sources) the same arithmetic picks for such a launch. */
 int nb_hip_plan_launch_unit(uint32_t n_recv, uint32_t n_src, int compute_units);

@@ -75,6 +75,7 @@ HIP_API = {
     "nb_hip_plan_launch": (None, [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "nb_hip_plan_launch_unit": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int]),
+    "nb_hip_plan_fused_finish": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int]),
     "nb_hip_plan_launch_lanes": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_int)]),
     "nb_hip_comm_unique_id": (None, [C.c_void_p]),
     "CreateSimPipelineSharded": (C.c_void_p, [WorldData, C.c_int, C.c_int, C.c_void_p]),
@@ -175,7 +176,8 @@ def plan_launch(n_recv, n_src, compute_units=256):
     hip_lib().nb_hip_plan_launch(n_recv, n_src, compute_units, C.byref(k), C.byref(w), C.byref(sp), C.byref(g))
     lanes = int(hip_lib().nb_hip_plan_launch_lanes(n_recv, n_src, C.byref(lw)))
     return {"k": k.value, "w": w.value, "split": sp.value, "workgroups": g.value,
-            "unit": int(hip_lib().nb_hip_plan_launch_unit(n_recv, n_src, compute_units)), "lanes": lanes, "lanes_w": lw.value}
+            "unit": int(hip_lib().nb_hip_plan_launch_unit(n_recv, n_src, compute_units)), "lanes": lanes, "lanes_w": lw.value,
+            "fused_finish": int(hip_lib().nb_hip_plan_fused_finish(n_recv, n_src, compute_units))}
 
 
 def comm_unique_id():

@@ -119,7 +119,7 @@ static double measure_large_n_rate(void) {
     int k = 0, wv = 0, split = 1;
     uint32_t groups = 0;
     nb_hip_plan_launch(CALIBRATION_N, m, 256, &k, &wv, &split, &groups);
-    const double kernels = split > 1 ? 2.0 : 1.0;
+    const double kernels = split > 1 && !nb_hip_plan_fused_finish(CALIBRATION_N, m, 256) ? 2.0 : 1.0;
     double busy = per_step - kernels * LAUNCH_FLOOR_US * 1e-6;
     if (busy <= 0.0) busy = per_step;
     return (double)CALIBRATION_N * (double)m / busy;
@@ -234,7 +234,9 @@ static int run_single(const Options *o) {
             nb_hip_plan_launch(n, (m + passes - 1) / passes, 256, &k, &wv, &split, &groups);
             /* lane-split steps (small worlds, every knob on auto) are one kernel whatever the classic plan's split says */
             const int lane_split = passes == 1 && nb_hip_plan_launch_lanes(n, m, NULL) > 1;
-            const double kernels = (double)passes * (split > 1 && !lane_split ? 2.0 : 1.0);
+            /* ... and steps whose last-arriving workgroup finishes its tile in the step kernel have no finish kernel */
+            const int fused = passes == 1 && nb_hip_plan_fused_finish(n, m, 256);
+            const double kernels = (double)passes * (split > 1 && !lane_split && !fused ? 2.0 : 1.0);
             const double floor_us = pairs / floor_rate * 1e6 + kernels * LAUNCH_FLOOR_US;
             printf("\t%11.3e\t%9.1f\t%8.2f\t%8.2f\t%9.1f", pairs / gpu_s, pairs / gpu_s * 14.0 / 157.3e12 * 100.0, gpu_s * 1e6,
                    floor_us, floor_us / (gpu_s * 1e6) * 100.0);

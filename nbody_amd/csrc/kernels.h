@@ -11,6 +11,8 @@ enum : uint32_t {
     STEP_ACC_IN = 1u,       // start each receiver's sum from acc[] instead of zero
     STEP_NO_FINALIZE = 2u,  // store the sums into acc[] and skip the integrator
 };
+// (experiment, knob "fused_finish") split steps without the finish kernel: the last-arriving workgroup of a receiver tile
+// adds the parts itself -- parts as agent-scope (sc1) stores / loads, one ticket per tile; see step_kernel<..., FUSED>
 
 enum : int {
     VARIANT_LDS = 0,   // wave-private LDS tiles (coalesced float2 loads -> ds_write -> broadcast ds_read_b128)
@@ -51,6 +53,7 @@ struct StepParams {
     // workgroup count near a round boundary (see choose_shape).
     float2 *parts;
     uint32_t split;
+    uint32_t *tickets;    // fused finish only: one arrival counter per receiver tile, zero between launches
     // granule of the source slicing: a wave's slice is a whole number of `unit` sources (64, or 32 / 16 / 8 for
     // latency-bound launches whose parts hold fewer 64-source chunks than the workgroup has waves -- with 64 only, a
     // part of 6 chunks keeps 6 of 16 waves busy).  Slices stay 8-aligned, so the scalar loads keep their alignment.
@@ -104,6 +107,7 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
 
 // Kernel entry point and grid for a shape; used both for direct launches and for graph nodes.
 const void *step_kernel_fn(LaunchShape s);
+const void *step_kernel_fused_fn(LaunchShape s);   // nullptr when the shape has no fused-finish instantiation
 dim3 step_grid(LaunchShape s, uint32_t n_recv);
 dim3 step_block(LaunchShape s);
 size_t step_lds_bytes(LaunchShape s, uint32_t n_src);   // dynamic LDS of the launch (0 except for lane-split shapes)

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
 // per SIMD) would mean ONE resident workgroup per CU instead of two.  The asm body needs 36 (SMEM, K <= 2) / 62 (LDS);
 // the second launch-bound argument (waves per SIMD) makes the limit explicit.  K = 4 then keeps its Kahan state in
 // scratch, touched only at block closes outside the inner loop, and runs as fast as K = 2.
-template <int K, int W, int VARIANT>
+template <int K, int W, int VARIANT, bool FUSED = false>
 __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (WAVE - 1);
@@ -448,7 +448,17 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
     // ---- combine the W slices in wave order, integrate, store -------------------------------------------
     auto finish = [&](uint32_t logical, float sx, float sy) {
         if (p.split > 1) {
-            if (logical < p.n_recv) p.parts[(size_t)blockIdx.y * p.n_recv + logical] = make_float2(sx, sy);
+            if (logical < p.n_recv) {
+                float2 *slot = &p.parts[(size_t)blockIdx.y * p.n_recv + logical];
+                if constexpr (FUSED) {
+                    // agent-scope relaxed store (one 8-byte access): written through to the point every XCD's loads of the
+                    // same scope read
+                    const uint64_t bits = (uint64_t)__float_as_uint(sx) | ((uint64_t)__float_as_uint(sy) << 32);
+                    __hip_atomic_store(reinterpret_cast<uint64_t *>(slot), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    *slot = make_float2(sx, sy);
+                }
+            }
         } else {
             finish_receiver(p, logical, sx, sy, dt);
         }
@@ -471,6 +481,62 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
                 sy = __fadd_rn(sy, t.y);
             }
             finish(recv_base + slot, sx, sy);
+        }
+    }
+
+    if constexpr (FUSED) {
+        // The last workgroup of this receiver tile to get here adds the parts, in part order like finish_kernel, and
+        // integrates.  Every thread's part stores have been acknowledged (vmcnt(0)) before the workgroup takes its ticket;
+        // the last arriver therefore finds all parts written, and reads them with the same scope they were written with.
+        if (p.split > 1) {
+            __shared__ uint32_t is_last;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t t = __hip_atomic_fetch_add(&p.tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                is_last = t == p.split - 1 ? 1u : 0u;
+                if (is_last) __hip_atomic_store(&p.tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+            }
+            __syncthreads();
+            if (is_last) {
+                for (uint32_t slot = tid; slot < WAVE * K; slot += WAVE * W) {
+                    const uint32_t logical = recv_base + slot;
+                    if (logical >= p.n_recv) continue;
+                    // like finish_kernel: every part load issued before the first use (unused slots re-read the last part
+                    // and are dropped by a select), or the loads would queue up behind each other's round trips
+                    uint64_t bits[MAX_SPLIT];
+#pragma unroll
+                    for (uint32_t s = 0; s < (uint32_t)MAX_SPLIT; s++)
+                        bits[s] = __hip_atomic_load(reinterpret_cast<const uint64_t *>(&p.parts[(size_t)(s < p.split ? s : p.split - 1) * p.n_recv + logical]),
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // the integrator's state rides the same round trip (finish_receiver would fetch it behind the sums)
+                    const uint32_t i = receiver_slot(p, logical);
+                    const float2 a0 = p.acc[i], v0 = p.vel[i], q0 = p.pos_in[i];
+                    float sx = 0.0f, sy = 0.0f;
+#pragma unroll
+                    for (uint32_t s = 0; s < (uint32_t)MAX_SPLIT; s++) {
+                        const float nx = __fadd_rn(sx, __uint_as_float((uint32_t)bits[s])), ny = __fadd_rn(sy, __uint_as_float((uint32_t)(bits[s] >> 32)));
+                        sx = s < p.split ? nx : sx;
+                        sy = s < p.split ? ny : sy;
+                    }
+                    // same arithmetic, same roundings as finish_receiver / finish_kernel
+                    float2 a = make_float2(sx, sy);
+                    if (p.flags & STEP_ACC_IN) {
+                        a.x = __fadd_rn(a0.x, a.x);
+                        a.y = __fadd_rn(a0.y, a.y);
+                    }
+                    p.acc[i] = a;
+                    if (p.flags & STEP_NO_FINALIZE) continue;
+                    float2 v = v0, q = q0;
+                    v.x = __fadd_rn(v.x, __fmul_rn(a.x, dt));
+                    v.y = __fadd_rn(v.y, __fmul_rn(a.y, dt));
+                    q.x = __fadd_rn(q.x, __fmul_rn(v.x, dt));
+                    q.y = __fadd_rn(q.y, __fmul_rn(v.y, dt));
+                    p.vel[i] = v;
+                    p.pos_out[i] = q;
+                    if (i < p.n_mirror) p.mirror[i] = q;
+                }
+            }
         }
     }
 }
@@ -843,6 +909,14 @@ const void *pick(int k, int w) {
     return nullptr;
 }
 
+const void *pick_fused(int k, int w) {
+#define NB_CASE(KK, WW) \
+    if (k == KK && w == WW) return reinterpret_cast<const void *>(&step_kernel<KK, WW, VARIANT_SMEM, true>);
+    NB_CASE(1, 4) NB_CASE(1, 8) NB_CASE(1, 16) NB_CASE(2, 4) NB_CASE(2, 8) NB_CASE(2, 16)
+#undef NB_CASE
+    return nullptr;
+}
+
 const void *pick_lane_split(int w, int h) {
 #define NB_CASE(WW, HH) \
     if (w == WW && h == HH) return reinterpret_cast<const void *>(&lane_split_kernel<WW, HH>);
@@ -1016,6 +1090,11 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
 const void *step_kernel_fn(LaunchShape s) {
     if (s.lanes > 1) return pick_lane_split(s.w, s.lanes);
     return s.variant == VARIANT_SMEM ? pick<VARIANT_SMEM>(s.k, s.w) : pick<VARIANT_LDS>(s.k, s.w);
+}
+
+const void *step_kernel_fused_fn(LaunchShape s) {
+    if (s.lanes > 1 || s.variant != VARIANT_SMEM) return nullptr;
+    return pick_fused(s.k, s.w);
 }
 
 dim3 step_grid(LaunchShape s, uint32_t n_recv) {

@@ -83,6 +83,8 @@ void release_device(SimPipeline *s) {
     dev_free(s->parts);
     s->parts = nullptr;
     s->parts_cap = 0;
+    dev_free(s->tickets);
+    s->tickets = nullptr;
     ASSERT_HIP(hipEventDestroy(s->ev_begin), "event");
     ASSERT_HIP(hipEventDestroy(s->ev_end), "event");
     ASSERT_HIP(hipEventDestroy(s->ev_local), "event");
@@ -220,6 +222,8 @@ SimPipeline *CreateSimPipeline(WorldData data) {
     if (ln) s->want_lanes = atoi(ln);
     const char *fc = getenv("NB_HIP_FUSED_CHAIN");
     if (fc) s->fused_chain = atoi(fc) < 0 || atoi(fc) > 2 ? 2 : atoi(fc);
+    const char *ff = getenv("NB_HIP_FUSED_FINISH");
+    if (ff) s->fused_finish = atoi(ff) < 0 || atoi(ff) > 2 ? 2 : atoi(ff);
     const char *gr = getenv("NB_HIP_GRAPH");
     if (gr) s->use_graph = atoi(gr) < 0 || atoi(gr) > 2 ? 2 : atoi(gr);
     return s;
@@ -282,6 +286,11 @@ int nb_hip_plan_launch_lanes(uint32_t n_recv, uint32_t n_src, int *w) {
     const int lanes = n_src <= nb::LANE_SPLIT_MAX_SRC ? nb::lane_split_rule(n_recv, n_src, &ww) : 1;
     if (w) *w = ww;
     return lanes;
+}
+
+int nb_hip_plan_fused_finish(uint32_t n_recv, uint32_t n_src, int compute_units) {
+    const nb::LaunchShape sh = nb::choose_shape({0, 0, nb::VARIANT_SMEM, 0, 0, 1}, n_recv, n_src, compute_units);
+    return sh.split > 1 && nb_hip_plan_launch_lanes(n_recv, n_src, nullptr) <= 1 && fused_finish_rule(n_recv, n_src) ? 1 : 0;
 }
 
 int nb_hip_plan_launch_unit(uint32_t n_recv, uint32_t n_src, int compute_units) {
@@ -606,6 +615,15 @@ int nb_hip_configure(SimPipeline *s, const char *key, int value) {
         NB_ASSERT(value >= 0 && value <= 2, "fused_chain must be 0 (never), 1 (whenever the world fits one workgroup) or 2 (auto), got %d", value);
         old = s->fused_chain;
         s->fused_chain = value;
+    } else if (!strcmp(key, "fused_finish")) {
+        NB_ASSERT(value >= 0 && value <= 2, "fused_finish must be 0 (never), 1 (whenever the shape allows) or 2 (auto), got %d", value);
+        old = s->fused_finish;
+        if (s->on_device && old != value) {
+            ASSERT_HIP(hipStreamSynchronize(s->stream), "sync before switching the finish mode");
+            for (auto &g : s->graphs) destroy_graph(g);   // cached chains hold the other kernel set
+            s->graphs.clear();
+        }
+        s->fused_finish = value;
     } else if (!strcmp(key, "passes")) {
         NB_ASSERT(value >= 0 && value <= 64, "passes must be 0 (auto) .. 64, got %d", value);
         old = s->want_passes;

@@ -212,6 +212,9 @@ struct SimPipeline {
     int timing = 0;
     float2 *parts = nullptr;    // split steps only: [split][n_real] partial sums
     uint32_t parts_cap = 0;     // float2 elements allocated in parts
+    uint32_t *tickets = nullptr;  // "fused_finish" experiment: one arrival counter per receiver tile (n_real / 64 + 1), zeroed
+    int fused_finish = 2;         // 0: step kernel + finish kernel; 1: the last workgroup of a tile finishes it, whenever
+                                  // the shape allows; 2 (default): auto (step_chain.hip fused_finish_rule)
     int cur = 0;             // pos[cur] is the latest state
 
     hipStream_t stream = nullptr;
@@ -259,5 +262,6 @@ void sharded_step(SimPipeline *s, nb::LaunchShape sh, float dt, hipStream_t cs, 
 // in-place all-gather of a device array of nranks slots through the caller's host transport
 void host_allgather(SimPipeline *s, void *dev_base, size_t bytes_per_rank, hipStream_t st);
 void enqueue_steps(SimPipeline *s, uint32_t n, float dt);  // what PerformSimUpdate / nb_hip_step_async enqueue
+bool fused_finish_rule(uint32_t n_recv, uint32_t n_src);   // the auto rule of the "fused_finish" knob (pure host)
 
 }  // namespace nbi

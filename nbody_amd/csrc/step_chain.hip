@@ -77,6 +77,12 @@ nb::LaunchShape resolve_shape(SimPipeline *s) {
             dev_free(s->parts);
             s->parts = dev_alloc<float2>(need);
             s->parts_cap = (uint32_t)need;
+            if (!s->tickets) {
+                const size_t tiles = (size_t)s->n_real / 64 + 2;
+                s->tickets = dev_alloc<uint32_t>(tiles);
+                ASSERT_HIP(hipMemsetAsync(s->tickets, 0, tiles * sizeof(uint32_t), s->stream), "zero the tile tickets");
+                ASSERT_HIP(hipStreamSynchronize(s->stream), "sync after zeroing the tickets");
+            }
             for (auto &g : s->graphs) destroy_graph(g);  // cached nodes point at the old buffer
             s->graphs.clear();
         }
@@ -119,9 +125,35 @@ nb::StepParams whole_step(const SimPipeline *s, int in, float dt) {
     return p;
 }
 
+// Fused finish ("fused_finish" knob): a split step WITHOUT its second, dependent kernel.  The parts of a receiver tile
+// are written with agent-scope (sc1) stores; every workgroup then takes a ticket of its tile, and the one that arrives
+// last -- all other parts are complete by then: each workgroup waits for its own stores (vmcnt(0)) before it draws --
+// reads the parts back with the same scope, adds them in part order exactly like finish_kernel and integrates.  Same
+// bits as the two-kernel form (the GPU suite runs green with it forced on; tools/fused_finish_soak.py: 20 000 steps at
+// N = 10 000 + 300 random shapes, 0 differences).  What it buys is the finish kernel's boundary minus the ticket's
+// round trip (profiles/r04_fused_finish.txt, us per step, cached graph replays | plain launches):
+//   N = 5 000 +0.6 | -0.6    8 000 0.0 | -0.5    10 000 -0.4 | -1.0    14 000 -1.2 | -0.8    20 000 -0.7 | -0.9
+//   50 000 -1.5 | -1.6    100 000 -2.3 | -2.3
+// Auto (2, default): unsharded steps on the scalar-cache route with N x M >= 4e7 (N >~ 9 000: from where it also wins
+// inside a hipGraph) and at most 200 000 receivers (beyond that the finish kernel is < 0.3 % of a step, and the kernels
+// of the BASELINE sizes stay the ones the PMC profiles describe).  Sharded steps keep the two-kernel form.
+constexpr double FUSED_FINISH_MIN_PAIRS = 4.0e7;
+constexpr uint32_t FUSED_FINISH_MAX_RECV = 200000;
+
+bool fused_finish_rule(uint32_t n_recv, uint32_t n_src) {
+    return (double)n_recv * (double)n_src >= FUSED_FINISH_MIN_PAIRS && n_recv <= FUSED_FINISH_MAX_RECV;
+}
+
+bool fused_finish_applies(const SimPipeline *s, nb::LaunchShape sh) {
+    if (s->fused_finish == 0 || s->sharded || sh.split <= 1 || sh.lanes > 1 || s->tickets == nullptr) return false;
+    if (nb::step_kernel_fused_fn(sh) == nullptr) return false;   // scalar-cache route, W >= 4
+    return s->fused_finish == 1 || fused_finish_rule(s->n_real, s->n_src);
+}
+
 nb::StepParams shaped(const SimPipeline *s, nb::StepParams p, nb::LaunchShape sh) {
     p.split = sh.split > 1 ? (uint32_t)sh.split : 1u;
     p.parts = p.split > 1 ? s->parts : nullptr;
+    p.tickets = s->tickets;
     // finer slice granules only for single-range steps (the overlapped sharded step walks two ranges: 64 there)
     p.unit = (sh.unit >= 8 && sh.unit <= 64 && p.src_end[1] == p.src_begin[1]) ? (uint32_t)sh.unit : 64u;
     return p;
@@ -162,13 +194,14 @@ std::vector<nb::StepParams> step_passes(const SimPipeline *s, const nb::StepPara
 
 void launch_step(SimPipeline *s, nb::LaunchShape sh, const nb::StepParams &p, hipStream_t st) {
     if (s->n_real == 0) return;  // a rank without receivers still takes part in the gathers
+    const bool fused = fused_finish_applies(s, sh);
     for (nb::StepParams &copy : step_passes(s, p, sh)) {
         void *args[] = {&copy};
-        ASSERT_HIP(hipLaunchKernel(nb::step_kernel_fn(sh), nb::step_grid(sh, s->n_real), nb::step_block(sh), args,
+        ASSERT_HIP(hipLaunchKernel(fused ? nb::step_kernel_fused_fn(sh) : nb::step_kernel_fn(sh), nb::step_grid(sh, s->n_real), nb::step_block(sh), args,
                                    nb::step_lds_bytes(sh, copy.src_end[0] - copy.src_begin[0]), st),
                    "step kernel launch (k=%d w=%d variant=%d split=%d, %u receivers)", sh.k, sh.w, sh.variant, sh.split,
                    s->n_real);
-        if (copy.split > 1)
+        if (copy.split > 1 && !fused)
             ASSERT_HIP(hipLaunchKernel(nb::finish_kernel_fn(), nb::finish_grid(s->n_real), nb::finish_block(), args, 0, st),
                        "finish kernel launch (%u receivers, %u parts)", s->n_real, copy.split);
     }
@@ -210,7 +243,8 @@ StepGraph *find_graph(SimPipeline *s, uint32_t n, uint32_t passes, nb::LaunchSha
 StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchShape sh) {
     const uint32_t passes = passes_for(s, whole_step(s, s->cur, dt));
     StepGraph *g = find_graph(s, n, passes, sh, s->cur);
-    const uint32_t per_pass = sh.split > 1 ? 2 : 1;  // step kernel (+ finish kernel)
+    const bool fused = fused_finish_applies(s, sh);
+    const uint32_t per_pass = sh.split > 1 && !fused ? 2 : 1;  // step kernel (+ finish kernel)
     const uint32_t per_step = passes * per_pass;
     const bool fresh = g == nullptr;
     if (fresh) {
@@ -235,7 +269,7 @@ StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchS
             for (uint32_t j = 0; j < per_pass; j++) {
                 hipKernelNodeParams kp;
                 if (j == 0)
-                    fill_node(kp, args, nb::step_kernel_fn(sh), nb::step_grid(sh, s->n_real), nb::step_block(sh),
+                    fill_node(kp, args, fused ? nb::step_kernel_fused_fn(sh) : nb::step_kernel_fn(sh), nb::step_grid(sh, s->n_real), nb::step_block(sh),
                               nb::step_lds_bytes(sh, launches[q].src_end[0] - launches[q].src_begin[0]));
                 else
                     fill_node(kp, args, nb::finish_kernel_fn(), nb::finish_grid(s->n_real), nb::finish_block());
@@ -589,7 +623,7 @@ void enqueue_steps(SimPipeline *s, uint32_t n, float dt) {
     s->timed = s->timing != 0;
     s->timed_launches = (s->sharded && s->overlap) ? 2 * n : n * passes_for(s, whole_step(s, s->cur, dt));
     if (s->fused_steps) s->timed_launches = (n + CHAIN_MAX_STEPS_PER_LAUNCH - 1) / CHAIN_MAX_STEPS_PER_LAUNCH;
-    s->timed_finish_launches = s->last_shape.split > 1 ? s->timed_launches : 0;
+    s->timed_finish_launches = s->last_shape.split > 1 && !fused_finish_applies(s, s->last_shape) ? s->timed_launches : 0;
     s->data.dt = dt;
 }
 

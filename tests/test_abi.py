@@ -157,6 +157,16 @@ def test_launch_plan_round_boundaries_and_splits():
     assert nb.plan_launch(1 << 20, 523884, compute_units=0)["k"] == 2                       # 0 CUs -> default 256
 
 
+def test_fused_finish_rule():
+    """nb_hip_plan_fused_finish: split steps run without the finish kernel from N x M >= 4e7 (where the in-kernel
+    hand-over also wins inside a hipGraph, profiles/r04_fused_finish.txt) up to 200 000 receivers; unsplit and lane-split
+    shapes have nothing to fuse."""
+    want = {(5000, 2439): 0, (8000, 3919): 0, (10000, 4917): 1, (14000, 6911): 1, (20000, 9956): 1, (50000, 24850): 1,
+            (100000, 49944): 1, (65536, 32641): 0, (262144, 130916): 0, (1 << 20, 523884): 0, (2000, 967): 0, (0, 0): 0}
+    for (n, m), fused in want.items():
+        assert nb.plan_launch(n, m)["fused_finish"] == fused, (n, m)
+
+
 def test_lane_split_rule_matches_the_committed_scan():
     """nb_hip_plan_launch_lanes: latency-bound unsharded steps (N x M <= 9e6) run as lane-split launches -- (lanes, w) read
     off profiles/r03_lane_split_scan.txt -- and nothing above that does (the scheme loses once a step is throughput)."""

@@ -714,6 +714,58 @@ def test_source_split_steps(golden, split, variant):
     assert chained.tobytes() == plain.tobytes()
 
 
+@pytest.mark.parametrize("n,frac", [(9000, 0.5), (12000, 0.3), (20011, 0.5), (700, 1.0)])
+def test_fused_finish_equals_the_two_kernel_form(n, frac):
+    """Split steps whose last-arriving workgroup per receiver tile adds the parts inside the step kernel (knob
+    "fused_finish": parts as agent-scope stores / loads, one ticket per tile) against the same shape with the finish
+    kernel: same part order, same roundings -> the same bits, as plain launches, as a hipGraph chain, with source passes
+    chained through acc[], for every (k, w) the route instantiates -- and both are the reference's step (float64 bound,
+    integrator bit-exact)."""
+    part, m = synth(n, frac, seed=n)
+    for knobs in (dict(), dict(k=1, w=4, split=13), dict(k=2, w=8, split=7), dict(k=2, w=16, split=2, passes=2),
+                  dict(k=1, w=16, split=16, unit=8), dict(k=1, w=8, split=3, passes=3)):
+        two = run(part, m, 1, 0.01, fused_finish=0, lanes=1, **knobs)
+        one = run(part, m, 1, 0.01, fused_finish=1, lanes=1, **knobs)
+        assert one.tobytes() == two.tobytes(), (n, knobs)
+        for graph in (0, 1):
+            assert run(part, m, 7, 0.01, fused_finish=1, lanes=1, graph=graph, **knobs).tobytes() == \
+                run(part, m, 7, 0.01, fused_finish=0, lanes=1, graph=graph, **knobs).tobytes(), (n, knobs, graph)
+    check_one_step(run(part, m, 1, 0.01, fused_finish=1, lanes=1, split=5), part, m, 0.01)
+
+
+def test_fused_finish_auto_policy():
+    """Auto: unsharded split steps on the scalar-cache route from N x M >= 4e7 up to 200 000 receivers run WITHOUT the finish
+    kernel; smaller worlds, the LDS-tile route, the BASELINE sizes and sharded steps keep it."""
+    def finish_launches(n, **knobs):
+        _, part, m = bench_universe(n)
+        sim = nb.SimPipeline(n, m)
+        sim.configure(**knobs)
+        sim.set_data(part)
+        sim.update(3, 0.01)
+        out = (sim.finish_launches(), sim.launch_shape()["split"], nb.plan_launch(n, m)["fused_finish"])
+        sim.close()
+        return out
+    f, split, planned = finish_launches(10000)
+    assert split > 1 and f == 0 and planned == 1                     # one kernel per step
+    f, split, planned = finish_launches(10000, fused_finish=0)
+    assert split > 1 and f == 3
+    f, split, planned = finish_launches(6000)
+    assert split > 1 and f == 3 and planned == 0                     # below the rule: loses inside a hipGraph
+    f, split, planned = finish_launches(6000, fused_finish=1)
+    assert split > 1 and f == 0
+    f, split, planned = finish_launches(10000, variant=0)
+    assert split > 1 and f == 3                                      # the LDS-tile route has no fused instantiation
+    f, split, planned = finish_launches(262144)
+    assert split > 1 and f > 0 and planned == 0                      # BASELINE sizes: the profiled two-kernel form
+    _, part, m = bench_universe(20000)
+    g = nb.LocalShardGroup(20000, m, 2, split=4)
+    g.set_data(part)
+    g.step(1, 0.01)                                                  # sharded steps keep the two-kernel form; parity:
+    sharded = g.get_data(0)
+    g.close()
+    check_one_step(sharded, part, m, 0.01)
+
+
 def test_source_split_more_parts_than_chunks():
     part, m = synth(300, 0.1, seed=2)       # ~30 sources = one chunk, 16 parts: most parts are empty
     got = run(part, m, 1, 0.02, split=16)

@@ -96,7 +96,7 @@ def test_step_kernels_fit_the_occupancy_the_launch_bounds_promise(isa):
         assert scratch == 0, f"{name}: {scratch} bytes of scratch (spills)"
         assert sgpr <= 102, f"{name}: {sgpr} SGPRs"
     # the default (scalar-cache) route keeps the asm body's footprint: well under the limit
-    smem = [v for n, _, _, v in step if n.endswith("ELi1EEEvNS_10StepParamsE")]
+    smem = [v for n, _, _, v in step if re.search(r"ELi1E(Lb[01]E)?EEvNS_10StepParamsE$", n)]
     assert smem and max(smem) <= 48, smem
 
 
