@@ -1490,6 +1490,10 @@ def test_auto_launch_shape_is_near_the_best_of_its_neighbours_on_this_box(n):
     again_us, _ = _replay_us_per_step(part, m)
     auto_us = min(auto_us, again_us)
     rows[0] = ("auto", auto_us, auto)
+    # the finish mode is an auto pick too (fused from N x M >= 4e7): the same shape with the finish kernel brought back
+    if auto["split"] > 1 and auto["lanes"] == 1:
+        us, sh = _replay_us_per_step(part, m, fused_finish=0)
+        rows.append(("auto, two-kernel finish", us, sh))
     best = min(r[1] for r in rows)
     print(f"\nN={n} M={m}: auto {auto} = {auto_us:.2f} us/step; best {best:.2f}")
     for name, us, sh in sorted(rows, key=lambda r: r[1]):
