@@ -149,3 +149,29 @@ def test_the_gravitational_constant_is_written_down_once(isa):
     for name, body in users.items():
         assert any(ins.startswith("v_mul_f32") for ins in body), name
         assert not any(literal in ins.lower() or re.search(r"\b10\.0\b", ins) for ins in body), (name, literal)
+
+
+def test_fused_finish_tail_uses_agent_scope_accesses_and_leaves_the_other_kernels_alone(isa):
+    """The fused-finish instantiations (step_kernel<K, W, SMEM, true>) hand the parts over with agent-scope accesses: one
+    8-byte `sc1` store per receiver, a wait for the workgroup's own stores before the ticket (`global_atomic_add` with
+    return), sixteen 8-byte `sc1` loads issued back to back in the last arriver's tail -- and no fence (`buffer_wbl2` /
+    `buffer_inv`, the L2 write-back that made round 1's first version 5-13x slower).  The unfused instantiations contain
+    none of it: their code is what it was."""
+    fn = functions(isa)
+    fused = {n: b for n, b in fn.items() if "step_kernel" in n and "Lb1EEEv" in n}
+    plain = {n: b for n, b in fn.items() if "step_kernel" in n and "Lb0EEEv" in n}
+    assert len(fused) == 6 and len(plain) >= 16
+    for name, body in fused.items():
+        text = "\n".join(body)
+        assert len(re.findall(r"global_store_dwordx2 .* sc1", text)) >= 1, name
+        assert len(re.findall(r"global_load_dwordx2 .* sc1", text)) >= 16, name
+        atom = [i for i, x in enumerate(body) if x.startswith("global_atomic_add")]
+        assert len(atom) == 1 and "sc0" in body[atom[0]], name                        # the ticket, with its return value
+        # order on the way to the ticket: the part store, a wait for it, the workgroup barrier, then the atomic
+        store = max(i for i, x in enumerate(body[:atom[0]]) if re.match(r"global_store_dwordx2 .* sc1", x))
+        wait = next(i for i in range(store + 1, atom[0]) if body[i].startswith("s_waitcnt vmcnt(0)"))
+        assert any(x.startswith("s_barrier") for x in body[wait + 1:atom[0]]), name
+        assert "buffer_wbl2" not in text and "buffer_inv" not in text, name
+    for name, body in plain.items():
+        text = "\n".join(body)
+        assert "global_atomic" not in text and not re.search(r"global_(load|store)\S* .* sc1", text), name
