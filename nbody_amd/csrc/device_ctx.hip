@@ -6,7 +6,7 @@
 // first needs the GPU (SetSimulationData), so CPU-only worlds never initialise HIP.
 #include "pipeline_internal.h"
 
-#define NB_HIP_VERSION 101  // 0.1.1
+#define NB_HIP_VERSION 200  // 0.2.0: + CreateSimPipelineShardedDirect, nb_hip_plan_fused_finish, the "fused_finish" knob
 
 namespace nbi {
 
