@@ -156,8 +156,9 @@ def test_bench_leg_guard_deadline_writes_the_line_and_exits():
 
 @pytest.mark.parametrize("world", [1, 2, 4])
 def test_rank_link_collectives_with_real_processes(world, tmp_path):
-    """nbody_amd/ranklink.py: `world` processes meet over the abstract Unix socket, then all-gather, broadcast, reduce and
-    barrier; no torch in the workers (asserted: importing it is what the link exists to avoid)."""
+    """nbody_amd/ranklink.py: `world` processes meet over the Unix socket in the user's 0700 directory, then all-gather,
+    broadcast, reduce and barrier; no torch and no pickle in the workers (asserted: importing torch is what the link exists to
+    avoid, and nothing received is ever unpickled)."""
     root = os.path.dirname(HERE)
     code = f"""
 import sys
@@ -165,7 +166,8 @@ sys.path.insert(0, {root!r})
 from nbody_amd.ranklink import RankLink
 rank, world = int(sys.argv[1]), int(sys.argv[2])
 link = RankLink(rank, world, name="nbody_test_{os.getpid()}_" + sys.argv[2], timeout_s=60)
-assert link.allgather(("r", rank)) == [("r", q) for q in range(world)]
+assert link.allgather(rank) == list(range(world))
+assert link.allgather([float(rank), 0.5]) == [[float(q), 0.5] for q in range(world)]
 assert link.broadcast(b"x" * 128 if rank == 0 else None) == b"x" * 128
 assert link.reduce([rank, -rank, 1.0], "max") == [world - 1.0, 0.0, 1.0]
 assert link.reduce([rank, -rank, 1.0], "min") == [0.0, -(world - 1.0), 1.0]
@@ -177,6 +179,8 @@ for _ in range(100):
     link.barrier()
 link.close()
 assert "torch" not in sys.modules
+import inspect, nbody_amd.ranklink as rl
+assert "pickle" not in inspect.getsource(rl).replace("unpickled", "")
 print("ok", rank)
 """
     procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(world)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -213,3 +217,64 @@ print("NOT REACHED")
     assert procs[0].returncode != 0 and procs[2].returncode != 0
     assert all("NOT REACHED" not in o[0] for o in outs)
     assert "ConnectionError" in outs[0][1] or "Connection" in outs[0][1] or "Broken" in outs[0][1]
+
+
+def test_rank_link_wire_format_is_closed():
+    """The link's wire format carries None, bytes, int64, float64 lists and one level of list -- and nothing else: what is
+    not in the format is refused at encode time, and bytes that are not a valid message raise instead of being interpreted
+    (no pickle on a local socket)."""
+    from nbody_amd import ranklink as rl
+    for obj in (None, b"", b"abc" * 1000, 0, -5, 2 ** 62, [1.0, -2.5], [], [None, b"x", 3, [0.25]], [[1.0], [2.0, 3.0]]):
+        data = rl.encode(obj)
+        back, end = rl.decode(data)
+        assert end == len(data) and back == (list(obj) if isinstance(obj, tuple) else obj)
+    for bad in ("text", 1.5, {"a": 1}, True, [[[1.0]]], [object()]):
+        with pytest.raises((TypeError, ValueError)):
+            rl.encode(bad)
+    import pickle
+    for junk in (b"", b"X", b"B\xff\xff\xff\xff\xff\xff\xff\x7f", b"F\xff\xff\xff\xff", b"L\x01\x00\x00\x00L\x00\x00\x00\x00",
+                 b"I\x00", pickle.dumps({"a": 1})):
+        with pytest.raises(ValueError):
+            rl.decode(junk)
+
+
+def test_rank_link_socket_lives_in_a_private_directory_and_refuses_strangers(tmp_path):
+    """The hub's socket is a file in a 0700 directory of this user, and a connection that does not answer the hub's nonce
+    with the run's token is dropped without taking a rank slot; the real rank still gets in afterwards."""
+    import socket
+    import stat
+    import threading
+    import time
+    from nbody_amd import ranklink as rl
+    d = rl.socket_dir()
+    st = os.lstat(d)
+    assert stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and (st.st_mode & 0o077) == 0
+    name = f"nbody_test_stranger_{os.getpid()}"
+    result = {}
+
+    def hub():
+        link = rl.RankLink(0, 2, name=name, timeout_s=60)
+        result["gathered"] = link.allgather(b"hub")
+        link.close()
+
+    t = threading.Thread(target=hub)
+    t.start()
+    path = os.path.join(d, name + ".sock")
+    for _ in range(500):
+        if os.path.exists(path):
+            break
+        time.sleep(0.01)
+    s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    s.connect(path)
+    nonce = rl.RankLink._recv(s)
+    assert isinstance(nonce, bytes) and len(nonce) == 16
+    rl.RankLink._send(s, [1, b"\0" * 32])      # claims rank 1 with a wrong token
+    s.settimeout(10)
+    assert s.recv(1) == b""                     # dropped
+    s.close()
+    peer = rl.RankLink(1, 2, name=name, timeout_s=60)
+    assert peer.allgather(b"peer") == [b"hub", b"peer"]
+    peer.close()
+    t.join(30)
+    assert result["gathered"] == [b"hub", b"peer"]
+    assert not os.path.exists(path)             # the name is free again once everybody is connected
