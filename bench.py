@@ -60,7 +60,7 @@ N_CONFIG5 = 1 << 22
 N_CONFIG2 = 1 << 16
 N_CONFIG3 = 1 << 18
 DT = 0.01
-KERNEL_SOURCES = ("nbody_amd/csrc/kernels.hip", "nbody_amd/csrc/kernels.h")
+KERNEL_SOURCES = ("nbody_amd/csrc/kernels.hip", "nbody_amd/csrc/kernels.h", "nbody_amd/csrc/interaction_asm.h")
 
 
 def make_workload(n, all_massive=False):
@@ -82,52 +82,145 @@ def make_workload(n, all_massive=False):
 
 # ---- CPU baseline ---------------------------------------------------------------------------------------------------
 
+def host_cpu_share():
+    """How many host threads the CPU legs may use, and why.  Derived from what the process is allowed to run on -- the
+    scheduler affinity mask and, where the container sets one, the cgroup CPU quota -- not from a literal.  Only when
+    neither narrows a big host (affinity == every core of a > 32-core machine, no quota) does the pool's documented share
+    apply (one GPU of this pool comes with 16 CPUs); NB_BENCH_CPU_THREADS overrides everything.  Everything consulted is
+    recorded on the line."""
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
+    count = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = max(1, int(float(q) / float(per) + 0.5))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+                if q > 0 and per > 0:
+                    quota = max(1, int(q / per + 0.5))
+        except (OSError, ValueError):
+            pass
+    threads, why = (affinity or count), "sched_getaffinity"
+    if quota is not None and quota < threads:
+        threads, why = quota, "cgroup cpu quota"
+    if why == "sched_getaffinity" and threads == count and count > 32:
+        threads, why = 16, "pool share (16 CPUs per GPU box; affinity and cgroup quota leave all %d cores open)" % count
+    env = os.environ.get("NB_BENCH_CPU_THREADS")
+    if env and env.isdigit() and int(env) > 0:
+        threads, why = int(env), "NB_BENCH_CPU_THREADS"
+    return {"threads": max(1, threads), "threads_from": why, "affinity_cores": affinity, "os_cpu_count": count,
+            "cgroup_cpu_quota": quota, "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS")}
+
+
 def host_cores():
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    return max(1, min(cores, 16))  # the GPU box gives one GPU a 16-CPU share
+    return host_cpu_share()["threads"]
+
+
+def _libgomp():
+    for name in ("libgomp.so.1", "libgomp.so"):
+        try:
+            return C.CDLL(name)
+        except OSError:
+            pass
+    return None
 
 
 def cpu_baseline(part, mass_len, budget_s=12.0):
-    """Reference AVX path timed on this box's host cores over a bounded sample of the same workload, and the product's
-    own UpdateWorld_CPU on the same receivers with the same number of threads."""
+    """The reference's own UpdateWorld_CPU (src/lib/world.c:99-110: PackParticles + the OpenMP schedule(static, 20) loop
+    over PackedUpdate, src/lib/sim_cpu.c:156-194), compiled where it lies into oracle/_ref/libnbody_ref_world.so, timed
+    on this box's host cores over a bounded sample of the same workload; beside it the product's UpdateWorld_CPU on the
+    same World with the same number of threads.  Fallbacks, in order, when that library is absent: the
+    reference's PackedUpdate object code driven per receiver from Python threads (oracle/_ref/libnbody_ref_cpu.so), then
+    the oracle's AVX restatement (kind "port")."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
 
-    cores = host_cores()
+    share = host_cpu_share()
+    cores = share["threads"]
     n = part.shape[0]
-    # ~2e9 interactions/s/core (SURVEY.md section 6): size the receiver sample for about budget_s seconds
+    # ~2e9 interactions/s/core (SURVEY.md section 6): size the receiver sample for about budget_s seconds.  The sample is
+    # a World of the first `recv` partitioned particles: massive particles come first, so it holds ALL mass_len sources
+    # and one UpdateWorld_CPU step of it evaluates exactly recv x mass_len interactions.
     recv = int(budget_s * 2.0e9 * cores / max(mass_len, 1))
-    recv = max(64 * cores, min(n, recv // (20 * cores) * (20 * cores)))
-    kind, threads = "port", cores
-    sec = None
-    if os.path.exists(ob.REF_CPU_SO):
+    recv = max(mass_len, min(n, recv // (20 * cores) * (20 * cores)))
+    kind, threads, sec, one, how = "port", cores, None, None, None
+    if os.path.exists(ob.REF_WORLD_SO):
+        try:
+            # untimed: bring the OpenMP team up and the host cores out of idle (on a virtualised host the first parallel
+            # region after an idle spell can run as good as serialised for a second) -- small steps for ~0.6 s
+            t_warm = time.perf_counter()
+            while time.perf_counter() - t_warm < 0.6:
+                _time_reference_world(ob.REF_WORLD_SO, part, min(n, 8192), cores, steps=20)
+            sec = _time_reference_world(ob.REF_WORLD_SO, part, recv, cores)
+            kind = "reference"
+            how = ("reference UpdateWorld_CPU (src/lib/world.c:99-110 + sim_cpu.c, compiled where it lies: "
+                   "oracle/_ref/libnbody_ref_world.so; its OpenMP loop, omp_set_num_threads(%d))" % cores)
+            # SURVEY.md 8d also asks for the 1-thread figure: ~2 s of the same call on one thread
+            recv1 = max(64, min(n, int(2.0 * 2.0e9 / max(mass_len, 1))))
+            one = recv1 * min(mass_len, recv1) / _time_reference_world(ob.REF_WORLD_SO, part, recv1, 1)
+        except Exception as e:  # pragma: no cover - diagnostic only
+            print(f"[bench] reference UpdateWorld_CPU leg failed ({e}); falling back", file=sys.stderr)
+            sec = None
+    if sec is None and os.path.exists(ob.REF_CPU_SO):
         try:
             sec = _time_reference_packedupdate(ob.REF_CPU_SO, part, mass_len, recv, cores)
             kind = "reference"
+            how = "reference PackedUpdate object code (oracle/_ref/libnbody_ref_cpu.so) driven per receiver from Python threads"
         except Exception as e:  # pragma: no cover - diagnostic only
-            print(f"[bench] reference CPU leg failed ({e}); using the port", file=sys.stderr)
-    one = None
+            print(f"[bench] reference PackedUpdate leg failed ({e}); using the port", file=sys.stderr)
+            sec = None
     if sec is None:
         sec, threads, _ = ob.time_avx_sample(part, mass_len, 0, recv, dt=DT, threads=cores)
-    else:
-        # SURVEY.md 8d also asks for the 1-thread figure: ~2 s of the same loop on one core
-        recv1 = max(64, min(n, int(2.0 * 2.0e9 / max(mass_len, 1))))
-        one = recv1 * mass_len / _time_reference_packedupdate(ob.REF_CPU_SO, part, mass_len, recv1, 1)
+        how = "oracle/nbody_oracle.c AVX restatement (bit-exact with the reference's AVX build)"
     out = {
         "value": recv * mass_len / sec,
         "unit": "interactions/s",
         "cores": threads,
         "kind": kind,
+        "how": how,
         "cpu_model": _cpu_model(),
         "value_1_thread": one,
-        "sample": f"{recv} of {n} receivers x all {mass_len} sources, one step, AVX (-mavx, no FMA) + {threads} threads"
-                  f" ({sec:.2f} s); whole step would take ~{sec * n / recv:.0f} s",
+        "sample": f"World of the first {recv} of {n} partitioned particles (all {mass_len} sources), one step, AVX (-mavx, no FMA) "
+                  f"+ {threads} threads ({sec:.2f} s); the whole step would take ~{sec * n / recv:.0f} s",
     }
+    out.update({k: share[k] for k in ("threads_from", "affinity_cores", "os_cpu_count", "cgroup_cpu_quota", "OMP_NUM_THREADS")})
     try:
         out["product"] = product_cpu_leg(part, mass_len, recv, threads)
     except Exception as e:  # pragma: no cover - diagnostic only
         out["product"] = {"error": str(e)}
     return out
+
+
+def _time_reference_world(so, part, recv, threads, steps=1):
+    """Seconds of ONE UpdateWorld_CPU(dt, steps) of the reference's own world.c on a World of part[:recv].  The library's five
+    sim_gpu.h symbols bind to libnbody_hip.so (loaded first, RTLD_GLOBAL); CreateSimPipeline allocates nothing on a GPU and
+    nothing else of the seam is called by a CPU step, so no GPU is touched.  RTLD_DEEPBIND: the reference's calls into its
+    own sim_cpu.c must resolve inside its library, whatever else this process has loaded."""
+    import nbody_amd as nb
+
+    nb.hip_lib()
+    ref = C.CDLL(so, mode=os.RTLD_NOW | os.RTLD_LOCAL | getattr(os, "RTLD_DEEPBIND", 0))
+    ref.CreateWorld.restype = C.c_void_p
+    ref.CreateWorld.argtypes = [C.c_void_p, C.c_uint32]
+    ref.UpdateWorld_CPU.restype = None
+    ref.UpdateWorld_CPU.argtypes = [C.c_void_p, C.c_float, C.c_uint32]
+    ref.DestroyWorld.restype = None
+    ref.DestroyWorld.argtypes = [C.c_void_p]
+    gomp = _libgomp()
+    if gomp is not None:
+        gomp.omp_set_num_threads(C.c_int(threads))
+    sample = np.ascontiguousarray(part[:recv])
+    w = ref.CreateWorld(sample.ctypes.data, recv)   # copies and partitions (already partitioned: order unchanged)
+    try:
+        t0 = time.perf_counter()
+        ref.UpdateWorld_CPU(w, DT, steps)
+        return time.perf_counter() - t0
+    finally:
+        ref.DestroyWorld(w)
 
 
 def product_cpu_leg(part, mass_len, recv, threads):
@@ -137,13 +230,7 @@ def product_cpu_leg(part, mass_len, recv, threads):
     import nbody_amd as nb
 
     recv = max(recv, mass_len)  # the sources must all be in the World
-    gomp = None
-    for name in ("libgomp.so.1", "libgomp.so"):
-        try:
-            gomp = C.CDLL(name)
-            break
-        except OSError:
-            pass
+    gomp = _libgomp()
     if gomp is not None:
         gomp.omp_set_num_threads(C.c_int(threads))
     w = nb.World(part[:recv])
@@ -212,7 +299,10 @@ def parity_stamp(sim, mass_len, dt=DT, samples=256):
     import oracle_binding as ob
 
     before = sim.get_data()
-    sim.update(1, dt)
+    if hasattr(sim, "update"):
+        sim.update(1, dt)
+    else:
+        sim.step(1, dt)    # a LocalShardGroup: all P shards of one world advance together
     after = sim.get_data()
     n = before.shape[0]
     rng = np.random.default_rng(20260401)
@@ -311,6 +401,45 @@ def algorithmic_bytes_per_launch(n, m, passes):
     return (reads + writes) / passes
 
 
+MIX_FLOOR_CYCLES = 26.0   # 9 plain fp32 VALU instructions at 2 issue cycles + one v_rsq_f32 at 8
+NOMINAL_CLOCK_GHZ = 2.4   # MI355X_MICROARCH.md "Max clock"; the 157.3 TFLOP/s peak is quoted at it
+
+
+def device_cus(device_info):
+    """Compute units out of nb_hip_device_info's "name arch CUs clockMHz pci=..." (the token after the gfx arch)."""
+    tok = str(device_info).split()
+    for i, t in enumerate(tok):
+        if t.startswith("gfx") and i + 1 < len(tok) and tok[i + 1].isdigit():
+            return int(tok[i + 1])
+    return 256
+
+
+def held_clock_fields(clock, per_launch_s, launch_interactions, device_info, achieved_tflops):
+    """roofline.held_clock_ghz and what follows from it: how many shader cycles one wave-interaction of the TIMED kernel
+    took on every SIMD (kernel seconds x held clock x SIMDs / wave-interactions), which fraction of the instruction mix's
+    26-cycle floor that is, and the roofline fraction re-priced at the held clock instead of the nominal 2.4 GHz."""
+    if not clock or "clock_ghz" not in clock or per_launch_s <= 0 or launch_interactions <= 0:
+        return {"held_clock_ghz": None, "clock_probe": clock}
+    cus = device_cus(device_info)
+    simds = 4 * cus
+    ghz = clock["clock_ghz"]
+    cycles = per_launch_s * ghz * 1e9 * simds / (launch_interactions / 64.0)
+    return {
+        "held_clock_ghz": ghz,
+        "cycles_per_wave_interaction": cycles,
+        "frac_of_mix_ceiling": MIX_FLOOR_CYCLES / cycles,
+        "frac_at_held_clock": achieved_tflops / (PEAK_FP32_VECTOR_TFLOPS * ghz / NOMINAL_CLOCK_GHZ),
+        # one wave-interaction = 14 x 64 counted flops; the peak is 64 flop per cycle and SIMD (157.3e12 / 1024 / 2.4e9)
+        "mix_ceiling_frac_at_nominal_clock": FLOP_PER_INTERACTION / MIX_FLOOR_CYCLES,
+        "clock_probe": dict(clock, note="nb_hip_probe_clock right after the timed steps, outside the timed region: a separate kernel "
+                                        "with the step kernels' interaction statement on scalar operands, 8 waves per SIMD on every "
+                                        "CU, ~40 ms; held clock = median over its waves of d(s_memtime) / d(s_memrealtime) x the "
+                                        "reference rate; its own cycles_per_wave_interaction is the pure loop's (no loads, no "
+                                        "epilogue); cycles_per_wave_interaction above = timed kernel seconds x held clock x "
+                                        f"{simds} SIMDs / wave-interactions; floor of this instruction mix = {MIX_FLOOR_CYCLES:g} cycles"),
+    }
+
+
 # ---- deadline guard of the optional legs --------------------------------------------------------------------------------
 
 class LastGasp:
@@ -373,7 +502,7 @@ class LegGuard:
             os._exit(4)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -382,8 +511,10 @@ def main():
                     help="particles (default 2^20, the size the metric is quoted on); not --n: torchrun claims that prefix")
     ap.add_argument("--extra-particles", dest="n5", type=int, default=N_CONFIG5,
                     help="size of the second sharded workload under extra_configs (default 2^22 = BASELINE.json config 5)")
-    ap.add_argument("--transport", choices=("rccl", "host", "direct"), default="rccl",
-                    help="N > 1: rccl = in-stream ncclAllGather (the product path); direct = no RCCL: every rank pushes its slice "
+    ap.add_argument("--transport", choices=("auto", "rccl", "host", "direct"), default="auto",
+                    help="N > 1: auto (default) = rccl, and if any rank of that attempt leaves before the headline is in hand, a FRESH "
+                         "set of rank processes with the direct exchange (the line is stamped transport_fallback); "
+                         "rccl = in-stream ncclAllGather (the product path); direct = no RCCL: every rank pushes its slice "
                          "device-to-device into its peers' IPC-mapped source arrays, one barrier per step over the rendezvous link "
                          "(the fallback should RCCL not come up); host = data staged through the host over the rendezvous link "
                          "(slow).  direct and host let several ranks share ONE GPU, where RCCL refuses duplicate devices")
@@ -391,6 +522,8 @@ def main():
                     help="N > 1: how the ranks meet on the host.  socket = a stdlib Unix-socket hub (no torch import: the run "
                          "binds /opt/rocm's HIP runtime and librccl); gloo = torch.distributed (torch's bundled runtime loads first)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clock-probe", action="store_true",
+                    help="skip the 40 ms clock probe after the headline leg (roofline.held_clock_ghz and what follows from it)")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the parity stamps (one extra step per leg, checked against the oracle, outside the timed regions)")
     ap.add_argument("--no-extras", action="store_true",
@@ -411,15 +544,27 @@ def main():
     ap.add_argument("--crash-leg", default=None,
                     help="rehearsal only (host transport): rank 0 abort()s inside this leg's all-gather, to exercise the "
                          "last-gasp line")
-    args = ap.parse_args()
+    ap.add_argument("--rehearse-rccl-failure", action="store_true",
+                    help="rehearsal only: in an rccl attempt the last rank leaves with exit code 3 right after the rendezvous, like the "
+                         "library's watchdog does when ncclCommInitRank never completes -- exercises --transport auto's fallback")
+    ap.add_argument("--attempt-timeout-s", type=float, default=900.0,
+                    help="N > 1: the supervisor ends (by exact pid) rank processes of an attempt that runs longer than this")
+    return ap.parse_args(argv)
+
+
+def worker_main(args):
+    """One rank: everything that touches the GPU happens in a process that runs this (and nothing else) exactly once."""
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+            sys.exit("bench.py worker: --gpus N > 1 without WORLD_SIZE (the supervisor in main() sets it)")
         args.gpus = world
+    attempt = int(os.environ.get("NB_BENCH_ATTEMPT", "0"))
+    if args.transport == "auto":
+        args.transport = "rccl"   # the supervisor passes an explicit transport to every attempt; a lone rank has no fallback to make
 
     # stdout carries exactly one line, the JSON: RCCL prints a version banner to stdout from native code, so the
     # process' fd 1 is pointed at stderr for the duration and the line is written to the saved descriptor at the end
@@ -453,7 +598,13 @@ def main():
         else:
             from nbody_amd.ranklink import RankLink
 
-            link = RankLink(rank, world)
+            link = RankLink(rank, world, name="nbody_bench_%s_%s_a%d" % (os.environ["MASTER_PORT"],
+                                                                        os.environ.get("TORCHELASTIC_RUN_ID", "none"), attempt))
+            if args.rehearse_rccl_failure and args.transport == "rccl" and world > 1:
+                link.barrier()
+                if rank == world - 1:
+                    print(f"[bench] rank {rank}: rehearsing an RCCL bootstrap that never completes: exit 3", file=sys.stderr, flush=True)
+                    os._exit(3)
     elif world > 1:
         sys.exit("WORLD_SIZE > 1 without a torch.distributed.run rendezvous (RANK / MASTER_PORT missing)")
 
@@ -588,7 +739,7 @@ def main():
         t0 = time.perf_counter()
         barrier()
         elapsed = reduce([max(time.perf_counter() - t0, 1e-9)], "max")[0]
-        kernel_ms, launches, finish_launches = 0.0, 0, 0
+        kernel_ms, launches, finish_launches, clock = 0.0, 0, 0, None
         shape, info = nb.plan_launch(plan["mass_count"] + plan["zero_count"], plan["src_padded"]), "dry-run"
         if sharded:
             extras["rccl"] = {"nranks_reported": {"min": None, "max": None}, "user_ranks": None, "devices": None,
@@ -604,6 +755,15 @@ def main():
         elapsed = timed_leg(sim, args.steps, args.warmup)
         steps_done = args.warmup + args.steps
         kernel_ms, launches = sim.last_step_ms()
+        # the clock the chip holds for this kind of work, asked right after the timed steps and outside them: a separate
+        # probe kernel with the step kernels' instruction mix (include/nbody_hip.h nb_hip_probe_clock); the product
+        # kernels carry no stamps
+        clock = None
+        if rank == 0 and not args.no_clock_probe:
+            try:
+                clock = nb.probe_clock(40.0)
+            except Exception as e:  # pragma: no cover - diagnostic only
+                clock = {"error": str(e)}
         finish_launches = sim.finish_launches()
         shape = sim.launch_shape()
         info = nb.device_info()
@@ -657,6 +817,7 @@ def main():
             "kernel_ms_per_launch": per_launch_s * 1e3,
             "launches": launches,
             "finish_launches": finish_launches,
+            **held_clock_fields(clock, per_launch_s, launch_interactions, info, achieved_tflops),
             "kernel_ms_note": ("HIP events on the launch stream around the whole chain / step-kernel launches"
                                + ("; each interval also holds one O(N) finish kernel (~9 us at 2^20) per step launch"
                                   if finish_launches else "")
@@ -710,7 +871,7 @@ def main():
                 out[key] = val
 
     # ---- optional legs ------------------------------------------------------------------------------------------
-    if sharded and not args.no_extras:
+    if sharded:
         guard = LegGuard(rank, lambda leg: emit({"extras_aborted": leg}), args.leg_deadline_s) if not args.dry_run else None
         gasp = LastGasp(json_fd) if (rank == 0 and not args.dry_run) else None
 
@@ -729,7 +890,7 @@ def main():
             _ = new_unique_id()
             p5 = nb.shard_plan(part5.shape[0], m5, rank, world)
             assert p5["src_padded"] >= m5
-            put("extra_configs", [
+            put("extra_configs", [] if args.no_extras else [
                 _extra_entry(n, mass_len, 1, 0, args.steps, 0.0, None, world),
                 _extra_entry(n, mass_len, 0, 1, args.steps, 0.0, None, world),
                 _extra_entry(part5.shape[0], m5, 0, 0, 3, 0.0, None, world),
@@ -737,23 +898,45 @@ def main():
             ] + ([dict(_extra_entry(n, mass_len, 0, 0, args.steps, 0.0, None, world), transport="direct (dry run)")]
                  if host_gather is None else []))
         else:
-            # every rank must hold the same full state, and it must be the single-GPU state of the same steps
+            # NOT optional for any N > 1 headline (--no-extras keeps it): every rank must hold the same full state, and it must
+            # be the single-GPU state of the same steps -- the check that would catch a stale or torn exchange
+            single_gpu_state = {}
+
+            def self_check(pipeline, steps_run):
+                got = pipeline.get_data()  # collective
+                check = {"ranks_agree": digests_agree(hashlib.sha256(got.tobytes()).digest()), "steps": steps_run}
+                if rank == 0:
+                    if steps_run not in single_gpu_state:
+                        one = nb.SimPipeline(n, mass_len)
+                        one.set_data(part)
+                        one.update(steps_run, DT)
+                        single_gpu_state[steps_run] = one.get_data()
+                        one.close()
+                    want = single_gpu_state[steps_run]
+                    dp = (got[:, 0:2].astype(np.float64) - want[:, 0:2]).ravel()
+                    check["vs_single_gpu_rel_l2_pos"] = float(np.sqrt(dp @ dp) / np.linalg.norm(want[:, 0:2].astype(np.float64)))
+                    check["vs_single_gpu_max_abs_pos"] = float(np.abs(dp).max())
+                    check["static_fields_equal"] = bool(np.array_equal(got[:, 6:8], want[:, 6:8]))
+                    # the sharded sum differs from the single-GPU one only in the order M terms are added (1e-4: DESIGN.md section 5)
+                    check["ok"] = bool(check["ranks_agree"] and check["static_fields_equal"] and check["vs_single_gpu_rel_l2_pos"] <= 1e-4)
+                # which physical devices took part: PCI addresses (ordinals can all read 0 when every rank sees one GPU)
+                pci = nb.device_info().split("pci=")[-1].encode()
+                seen = sorted(set(link.allgather(pci))) if link is not None else [pci]
+                check["devices"] = [d.decode() for d in seen]
+                check["crossed_devices"] = len(seen) > 1
+                barrier()
+                return check
+
             leg("self_check")
-            got = sim.get_data()  # collective
-            check = {"ranks_agree": digests_agree(hashlib.sha256(got.tobytes()).digest()),
-                     "steps": steps_done}
-            if rank == 0:
-                one = nb.SimPipeline(n, mass_len)
-                one.set_data(part)
-                one.update(steps_done, DT)
-                want = one.get_data()
-                one.close()
-                dp = (got[:, 0:2].astype(np.float64) - want[:, 0:2]).ravel()
-                check["vs_single_gpu_rel_l2_pos"] = float(np.sqrt(dp @ dp) / np.linalg.norm(want[:, 0:2].astype(np.float64)))
-                check["vs_single_gpu_max_abs_pos"] = float(np.abs(dp).max())
-                check["static_fields_equal"] = bool(np.array_equal(got[:, 6:8], want[:, 6:8]))
-            barrier()
-            put("self_check", check)
+            put("self_check", self_check(sim, steps_done))
+            if args.no_extras:
+                if guard:
+                    guard.disarm()
+                if gasp:
+                    gasp.disarm()
+                sim.close()
+                sim = None
+        if not args.dry_run and not args.no_extras:
             extra = []
             put("extra_configs", extra)   # the list grows in place: a deadline line carries the legs that finished
             # the overlapped step on the same pipeline
@@ -800,6 +983,12 @@ def main():
                 ed = timed_leg(simd, args.steps, 1)
                 entry = _extra_entry(n, mass_len, 0, 0, args.steps, ed, sharded_detail(simd, args.steps), world)
                 entry["transport"] = "direct (device-to-device pushes into IPC-mapped peers, one host barrier per step)"
+                # checked like the headline: same bytes on every rank, and the single-GPU state of the same steps
+                entry["self_check"] = self_check(simd, 1 + args.steps)
+                entry["cross_device_parity"] = ("pinned by this run: the ranks sat on different devices and the self-check passed"
+                                                if entry["self_check"]["crossed_devices"] and entry["self_check"].get("ok", True) else
+                                                "unpinned across devices: every rank of this run sat on the same device"
+                                                if not entry["self_check"]["crossed_devices"] else "FAILED across devices")
                 extra.append(entry)
                 simd.close()
             if guard:
@@ -825,7 +1014,24 @@ def main():
         sim.close()
         sim = None
         if not args.all_massive and args.n == N_PARTICLES and not args.no_extra_configs:
-            put("extra_configs", single_gpu_configs(nb, stamp=not args.no_parity))
+            # the library's error convention is abort(): from here on a fatal signal still writes the line in hand
+            gasp = LastGasp(json_fd) if rank == 0 else None
+
+            def arm(name):
+                if gasp:
+                    with out_lock:
+                        gasp.arm((json.dumps(dict(out, extras_aborted=f"{name} (fatal signal)")) + "\n").encode())
+
+            arm("extra_configs C2/C3/N2/C1")
+            configs = single_gpu_configs(nb, stamp=not args.no_parity)
+            put("extra_configs", configs)
+            arm("extra_configs S2/S4/S8/C5S8")
+            try:
+                configs.extend(shard_scaling_configs(nb, elapsed / args.steps * 1e3, stamp=not args.no_parity, n5=args.n5))
+            except Exception as e:  # pragma: no cover - diagnostic only
+                configs.append({"config": "S2/S4/S8/C5S8", "error": str(e)})
+            if gasp:
+                gasp.disarm()
     if sim is not None:
         sim.close()
 
@@ -943,6 +1149,81 @@ def single_gpu_configs(nb, stamp=True):
     return out
 
 
+XGMI_LINK_GBS = 153.0            # per direction and link, 7 links per GPU (task brief)
+GATHER_LATENCY_ASSUMED_MS = 0.05  # fixed cost of one small in-stream all-gather: an ASSUMPTION, never measured on > 1 device here
+
+
+def gather_estimate_ms(mass_chunk, ranks):
+    """What one per-step all-gather of `mass_chunk` float2 per rank should cost across `ranks` GPUs: every slice rides its
+    own xGMI link (direct all-gather), plus an assumed fixed latency.  An estimate with its source stated --
+    the only multi-GPU term of the curve that a single-GPU box cannot measure."""
+    wire = mass_chunk * 8.0 / (XGMI_LINK_GBS * 1e9) * 1e3 if ranks > 1 else 0.0
+    return wire + (GATHER_LATENCY_ASSUMED_MS if ranks > 1 else 0.0)
+
+
+def shard_leg(nb, name, part, m, ranks, steps, t1_ms=None, stamp=True):
+    """One rank's share of a sharded step, timed on ONE GPU: all `ranks` shards of the world live in this process
+    (nb_hip_local_group_*: the same shard plan, kernels, launch shape and mirror / gather layout as the RCCL path, the
+    exchange replaced by device-to-device copies on the same device) and advance together; every member's kernels carry
+    their own HIP event pairs, so the entry reports what ONE rank's N/P receivers x all M sources cost -- the compute half
+    of the 1/2/4/8 curve -- beside the estimated gather."""
+    n = part.shape[0]
+    grp = nb.LocalShardGroup(n, m, ranks)
+    grp.set_data(part)
+    grp.step(1, DT)   # warm-up (first launch of this shape, parts buffer)
+    t0 = time.perf_counter()
+    grp.step(steps, DT)
+    wall = (time.perf_counter() - t0) / steps
+    kernel, push = [], []
+    for mem in grp.members:
+        covered, k_ms, c_ms = mem.step_breakdown()
+        kernel.append(k_ms / max(covered, 1))
+        push.append(c_ms / max(covered, 1))
+    plan = nb.shard_plan(n, m, 0, ranks)
+    shard_ms = max(kernel)
+    gather_ms = gather_estimate_ms(plan["mass_chunk"], ranks)
+    entry = {
+        "config": name,
+        "workload": f"srand(11037) MakeGalaxies({n}, 2), N={n}, mass_len={m}, dt={DT}: ONE rank's step of a {ranks}-way sharded run "
+                    f"({plan['mass_count'] + plan['zero_count']} receivers x all {plan['src_padded']} gathered sources), plain launches, "
+                    f"timed for every one of the {ranks} shards on one GPU (local group: the exchange is a device copy, not RCCL)",
+        "ranks": ranks, "steps": steps,
+        "kernel": grp.members[0].launch_shape(),
+        "shard_kernel_ms_per_step": {"min": min(kernel), "max": max(kernel), "mean": sum(kernel) / len(kernel)},
+        "local_push_ms_per_step": {"min": min(push), "max": max(push)},
+        "all_shards_wall_ms_per_step": wall * 1e3,
+        "interactions_per_rank_step": float(plan["mass_count"] + plan["zero_count"]) * float(m),
+        "roofline_frac_per_rank": (float(plan["mass_count"] + plan["zero_count"]) * float(m) * FLOP_PER_INTERACTION
+                                   / (shard_ms * 1e-3) / (PEAK_FP32_VECTOR_TFLOPS * 1e12)),
+        "gather_estimate_ms": gather_ms,
+        "gather_estimate_source": f"{plan['mass_chunk']} float2 per rank over its own xGMI link at {XGMI_LINK_GBS:g} GB/s (SURVEY.md 8e: direct "
+                                  f"all-gather, one slice per link) + {GATHER_LATENCY_ASSUMED_MS:g} ms assumed fixed latency; NOT measured: "
+                                  "no run of this repo has crossed xGMI",
+        "predicted_steps_per_sec": 1.0 / ((shard_ms + gather_ms) * 1e-3),
+        "predicted_interactions_per_sec": float(n) * float(m) / ((shard_ms + gather_ms) * 1e-3),
+    }
+    if t1_ms is not None:
+        entry["single_gpu_ms_per_step"] = t1_ms
+        entry["compute_scaling_efficiency"] = t1_ms / (ranks * shard_ms)
+        entry["predicted_scaling_efficiency"] = t1_ms / (ranks * (shard_ms + gather_ms))
+    if stamp:
+        entry["parity"] = parity_stamp(grp, m)
+    grp.close()
+    return entry
+
+
+def shard_scaling_configs(nb, t1_ms, stamp=True, n5=N_CONFIG5):
+    """extra_configs S2 / S4 / S8 (the headline workload cut 2 / 4 / 8 ways) and C5S8 (BASELINE.json config 5: N = 2^22, 8 ways):
+    the per-rank shard step measured on this one GPU, each with a parity stamp against float64."""
+    out = []
+    part, m = make_workload(N_PARTICLES)
+    for ranks in (2, 4, 8):
+        out.append(shard_leg(nb, f"S{ranks}", part, m, ranks, 3, t1_ms=t1_ms, stamp=stamp))
+    part5, m5 = make_workload(n5)
+    out.append(shard_leg(nb, "C5S8", part5, m5, 8, 2, stamp=stamp))
+    return out
+
+
 def _digests_agree(dist, torch, digest):
     """True when every rank's sha256 equals rank 0's."""
     if dist is None:
@@ -974,5 +1255,206 @@ def _extra_entry(n, m, overlap, sharded_graph, steps, elapsed, detail, world):
     return e
 
 
+# ---- N > 1: a GPU-free supervisor over fresh rank processes --------------------------------------------------------------
+
+RUNNING = -1000   # status of a rank process that has not ended yet (exit codes and -signal numbers are > -1000)
+
+
+class RankProcess:
+    """One worker (this file, NB_BENCH_WORKER=1) for one rank of one attempt, started by a process that never touches the
+    GPU.  Rank 0's stdout (the JSON line) is captured; every worker's stderr is forwarded as it comes and its tail kept."""
+
+    def __init__(self, argv, env, rank, capture_stdout):
+        self.rank = rank
+        self.lines, self.tail = [], []
+        self.proc = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                     stdout=subprocess.PIPE if capture_stdout else sys.stderr.fileno(), stderr=subprocess.PIPE)
+        self.threads = [threading.Thread(target=self._pump_err, daemon=True)]
+        if capture_stdout:
+            self.threads.append(threading.Thread(target=self._pump_out, daemon=True))
+        for t in self.threads:
+            t.start()
+
+    def _pump_out(self):
+        for raw in self.proc.stdout:
+            self.lines.append(raw.decode(errors="replace"))
+
+    def _pump_err(self):
+        for raw in self.proc.stderr:
+            text = raw.decode(errors="replace")
+            sys.stderr.write(text)
+            sys.stderr.flush()
+            self.tail.append(text)
+            del self.tail[:-40]
+
+    def status(self):
+        rc = self.proc.poll()
+        return RUNNING if rc is None else rc
+
+    def end(self):
+        """By exact pid: this Popen's own child, nothing matched by name."""
+        if self.proc.poll() is None:
+            self.proc.kill()
+
+    def finish(self):
+        self.proc.wait()
+        for t in self.threads:
+            t.join(5.0)
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _headline_of(lines, world, dry_run):
+    """(line dict or None, why not): the last JSON object rank 0 wrote, accepted when it is a complete headline -- metric and
+    value present and, for a real multi-rank run, a self-check that passed."""
+    for text in reversed(lines):
+        text = text.strip()
+        if not text.startswith("{"):
+            continue
+        try:
+            line = json.loads(text)
+        except ValueError:
+            continue
+        if "metric" not in line or "value" not in line:
+            return None, "rank 0 wrote a line without metric / value"
+        if world > 1 and not dry_run:
+            check = line.get("self_check")
+            if not check:
+                return None, "the line carries no self_check"
+            if not check.get("ranks_agree") or check.get("ok") is False:
+                return line, "self_check failed: " + json.dumps(check)
+        return line, None
+    return None, "rank 0 wrote no JSON line"
+
+
+def supervise(args, argv):
+    """`bench.py --gpus N` (N > 1) started bare, or started once per rank by torch.distributed.run: THIS process never makes
+    a GPU call.  Bare: it starts N fresh rank processes itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT in their
+    environment) -- the shape of the reference harness, one plain command (src/bench.c:41-74).  Under torch.distributed.run:
+    every rank process supervises ONE fresh worker and the supervisors keep each other informed over their own rank link.
+    Either way an attempt whose ranks do not all deliver -- RCCL that does not come up (the library's watchdog leaves with 3,
+    its error convention with abort()), a self-check that fails -- is followed, with --transport auto, by a SECOND attempt in
+    fresh processes over the direct exchange; the line then carries "transport_fallback".  Nothing is ever retried or
+    re-executed inside a process that has touched the GPU; stragglers are ended by exact pid.
+    Exit code: 0 when a complete headline (with a passing self-check) was written, whatever optional legs did afterwards --
+    their fate is on the line ("extras_aborted", launch.attempts[].child_rcs); otherwise the worst child code."""
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ
+    if under_launcher:
+        my_rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        local = [(my_rank, int(os.environ.get("LOCAL_RANK", my_rank)))]
+        port = os.environ["MASTER_PORT"]
+        mode = "torch.distributed.run: every rank process stays GPU-free and supervises one fresh worker"
+    else:
+        my_rank, world = 0, args.gpus
+        local = [(r, r) for r in range(world)]
+        port = str(_free_port())
+        mode = f"bare: bench.py started its {world} rank processes itself"
+    run_id = os.environ.get("TORCHELASTIC_RUN_ID", "none")
+    sup = None
+    if under_launcher and world > 1:
+        from nbody_amd.ranklink import RankLink
+        sup = RankLink(my_rank, world, name=f"nbody_sup_{port}_{run_id}")
+
+    def everyone(values):
+        """Status of every rank, indexed by rank (bare: they are all mine)."""
+        if sup is None:
+            return list(values)
+        return [v for row in sup.allgather([float(v) for v in values]) for v in (int(x) for x in row)]
+
+    # what the workers get: the same command line minus what the supervisor decides
+    passthrough, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+        elif a == "--transport":
+            skip = True
+        elif not a.startswith("--transport="):
+            passthrough.append(a)
+    transports = ["rccl", "direct"] if args.transport == "auto" else [args.transport]
+    attempts, line, why = [], None, "no attempt ran"
+    for attempt, transport in enumerate(transports):
+        env = dict(os.environ, NB_BENCH_WORKER="1", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   NB_BENCH_ATTEMPT=str(attempt), TORCHELASTIC_RUN_ID=run_id)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if len(transports) > 1 and attempt == 0:
+            env.setdefault("NB_HIP_COMM_TIMEOUT_S", "75")   # there is a fallback: do not sit out the library's 180 s
+        t0 = time.monotonic()
+        ranks = [RankProcess(passthrough + ["--transport", transport], dict(env, RANK=str(r), LOCAL_RANK=str(lr)), r, r == 0)
+                 for r, lr in local]
+        first_failure = None
+        while True:
+            mine = [p.status() for p in ranks]
+            seen = everyone(mine)
+            if all(v != RUNNING for v in seen):
+                break
+            now = time.monotonic()
+            if first_failure is None and any(v not in (RUNNING, 0) for v in seen):
+                first_failure = now
+            # a rank that left with an error takes the attempt with it: the others get a moment (rank 0 may be writing
+            # its line; the library's own watchdogs may still fire), then go -- by exact pid
+            if (first_failure is not None and now - first_failure > 20.0) or now - t0 > args.attempt_timeout_s:
+                for p in ranks:
+                    p.end()
+            time.sleep(0.25)
+        for p in ranks:
+            p.finish()
+        rcs = everyone([p.status() for p in ranks])
+        record = {"transport": transport, "child_rcs": rcs, "seconds": round(time.monotonic() - t0, 2)}
+        # every rank's last words, indexed by rank (under a launcher each supervisor holds one worker's)
+        tails = ["".join(p.tail)[-900:] for p in ranks]
+        if sup is not None:
+            tails = [t.decode(errors="replace") for t in sup.allgather(tails[0].encode())]
+        verdict = 0
+        if my_rank == 0:
+            line, why = _headline_of(ranks[0].lines, world, args.dry_run)
+            verdict = 1 if (line is not None and why is None) else 0
+            if not verdict:
+                # whose stderr explains it: a rank that left with something other than Python's generic 1, if there is one
+                bad = sorted(range(world), key=lambda r: (rcs[r] == 0, rcs[r] == 1))[0]
+                record["why_not"] = why
+                record["stderr_tail"] = f"[rank {bad}, rc {rcs[bad]}] " + tails[bad]
+        if sup is not None:
+            verdict = int(sup.broadcast(verdict if my_rank == 0 else None, src=0))
+        attempts.append(record)
+        if verdict:
+            break
+    if sup is not None:
+        sup.barrier()
+        sup.close()
+    if my_rank != 0:
+        return 0 if verdict else 1
+    launch = {"mode": mode, "attempts": attempts}
+    if verdict:
+        line["launch"] = launch
+        if len(attempts) > 1:
+            first = attempts[0]
+            line["transport_fallback"] = {"from": first["transport"], "to": attempts[-1]["transport"], "rc": first["child_rcs"],
+                                          "why": first.get("why_not"), "stderr_tail": first.get("stderr_tail", "")[-600:]}
+        print(json.dumps(line), flush=True)
+        return 0
+    # no complete headline from any attempt: still one line, saying so
+    partial = line if isinstance(line, dict) else {}
+    partial.update({"metric": partial.get("metric", "particle-pair interactions/sec at N=2^20"), "value": partial.get("value"),
+                    "unit": "interactions/s", "n_gpus": world, "error": why, "launch": launch})
+    print(json.dumps(partial), flush=True)
+    worst = [rc for a in attempts for rc in a["child_rcs"] if rc not in (0, RUNNING)]
+    return (abs(worst[0]) if worst else 1) or 1
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if os.environ.get("NB_BENCH_WORKER") == "1" or (args.gpus <= 1 and not launched):
+        worker_main(args)     # one rank; the only place a GPU is touched
+        return 0
+    return supervise(args, argv)
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -83,7 +83,7 @@ int nb_hip_device_count(void);
 /* Device ordinal this process' pipelines are created on (default: 0, or LOCAL_RANK for sharded ones). */
 void nb_hip_set_device(int ordinal);
 
-/* Fills buf (NUL-terminated, at most len bytes) with "name arch CUs clockMHz"; aborts without a GPU. */
+/* Fills buf (NUL-terminated, at most len bytes) with "name arch CUs clockMHz pci=domain:bus:device"; aborts without a GPU. */
 void nb_hip_device_info(char *buf, uint32_t len);
 
 /* PerformSimUpdate without the final host wait: enqueue n steps and return. */
@@ -135,6 +135,19 @@ int nb_hip_launch_unit(const SimPipeline *sim);
 
 /* hipRuntimeGetVersion() of the HIP runtime this process actually bound (0 when it cannot be asked). */
 int nb_hip_runtime_version(void);
+
+/*
+ * Measurement aid (no reference counterpart): the shader clock the chip holds under the step kernels' instruction mix.
+ * Runs a separate probe kernel -- the interaction statement of the step kernels on scalar source operands, two
+ * receivers per lane, 1024-thread workgroups filling every SIMD with 8 waves, no memory traffic in the loop -- for about
+ * target_ms milliseconds; every wave stamps s_memtime (shader cycles) and s_memrealtime (constant reference clock) around
+ * its loop.  *clock_ghz = median over the waves of d(memtime) / d(memrealtime) x the reference rate (min / max beside
+ * it); *cycles_per_wave_interaction = the median wave's shader cycles per interaction it issued, divided by the 8 waves
+ * that share a SIMD (26 = the floor of this instruction mix: 9 plain fp32 VALU at 2 cycles + one v_rsq_f32 at 8).  The
+ * product kernels carry no stamps.  Any out pointer may be NULL.  Returns the number of waves that reported.
+ */
+int nb_hip_probe_clock(double target_ms, double *clock_ghz, double *clock_ghz_min, double *clock_ghz_max,
+                       double *cycles_per_wave_interaction, double *elapsed_ms);
 
 /*
  * Optional: tell the pipeline which long-lived host array Set/GetSimulationData will be called with (the World's

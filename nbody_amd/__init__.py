@@ -65,6 +65,7 @@ HIP_API = {
                                    C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_char_p, C.c_uint32]),
     "nb_hip_graph_stats": (C.c_uint32, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "nb_hip_runtime_version": (C.c_int, []),
+    "nb_hip_probe_clock": (C.c_int, [C.c_double] + [C.POINTER(C.c_double)] * 5),
     "nb_hip_launch_unit": (C.c_int, [C.c_void_p]),
     "nb_hip_last_fused_steps": (C.c_uint32, [C.c_void_p]),
     "nb_hip_launch_lanes": (C.c_int, [C.c_void_p]),
@@ -162,6 +163,14 @@ def device_info():
     buf = C.create_string_buffer(256)
     hip_lib().nb_hip_device_info(buf, 256)
     return buf.value.decode()
+
+
+def probe_clock(target_ms=40.0):
+    """include/nbody_hip.h nb_hip_probe_clock: the shader clock held under the step kernels' instruction mix."""
+    v = [C.c_double(0.0) for _ in range(5)]
+    waves = hip_lib().nb_hip_probe_clock(float(target_ms), *[C.byref(x) for x in v])
+    return {"clock_ghz": v[0].value, "clock_ghz_min": v[1].value, "clock_ghz_max": v[2].value,
+            "cycles_per_wave_interaction": v[3].value, "elapsed_ms": v[4].value, "waves": int(waves)}
 
 
 def shard_plan(total_len, mass_len, rank, nranks):

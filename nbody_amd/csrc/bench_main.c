@@ -243,7 +243,8 @@ static int run_single(const Options *o) {
         }
         printf("\n");
         fflush(stdout);
-        if (o->use_cpu && o->use_gpu && o->verify_given && o->verify_steps > 0) bad = verify_backends(o, ps, n) || bad;
+        /* --verify K wants both paths' results, whichever columns were asked for (--gpu --verify K still steps a CPU World) */
+        if (o->use_gpu && o->verify_given && o->verify_steps > 0) bad = verify_backends(o, ps, n) || bad;
         free(ps);
     }
     free(universe);

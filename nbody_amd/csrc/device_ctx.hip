@@ -39,8 +39,9 @@ void ensure_device() {
               "device %d is %s; this library ships gfx950 (MI355X) code objects only", ord, prop.gcnArchName);
     g_dev.ordinal = ord;
     g_dev.compute_units = prop.multiProcessorCount;
-    snprintf(g_dev.info, sizeof g_dev.info, "%s %s %d %d", prop.name[0] ? prop.name : "AMD-GPU", prop.gcnArchName,
-             prop.multiProcessorCount, prop.clockRate / 1000);
+    // the PCI address is what tells two ranks' devices apart when each process sees its own GPU as ordinal 0
+    snprintf(g_dev.info, sizeof g_dev.info, "%s %s %d %d pci=%04x:%02x:%02x", prop.name[0] ? prop.name : "AMD-GPU", prop.gcnArchName,
+             prop.multiProcessorCount, prop.clockRate / 1000, prop.pciDomainID, prop.pciBusID, prop.pciDeviceID);
     g_dev.ready = true;
 }
 

@@ -321,12 +321,26 @@ void nb_hip_local_group_step(SimPipeline **sims, int nranks, uint32_t n, float d
     NB_ASSERT((int)g->members.size() == nranks, "group has %zu members, %d passed", g->members.size(), nranks);
     for (int r = 0; r < nranks; r++) NB_ASSERT(sims[r]->on_device, "member %d has no data", r);
     use_device();
-    for (int r = 0; r < nranks; r++) upload_dt(sims[r], dt);
+    for (int r = 0; r < nranks; r++) {
+        SimPipeline *s = sims[r];
+        s->pool.used = 0;
+        s->kernel_iv.clear();
+        s->comm_iv.clear();
+        s->detail_steps = 0;
+        upload_dt(s, dt);
+    }
+    // with the "timing" knob every member's kernels and pushes get their own event pairs, so that
+    // nb_hip_last_step_breakdown(member) says what ONE rank's shard step costs (bench.py S2 / S4 / S8)
     for (uint32_t i = 0; i < n; i++)
         for (int r = 0; r < nranks; r++) {
             SimPipeline *s = sims[r];
-            sharded_step(s, resolve_shape(s), dt, g->stream);
+            sharded_step(s, resolve_shape(s), dt, g->stream, s->timing != 0 && i < DETAIL_STEPS_MAX);
         }
+    for (int r = 0; r < nranks; r++) {
+        SimPipeline *s = sims[r];
+        s->detail_steps = s->timing ? (n < DETAIL_STEPS_MAX ? n : DETAIL_STEPS_MAX) : 0;
+        s->timed = false;   // no whole-chain event pair for group members; the breakdown has its own
+    }
     ASSERT_HIP(hipStreamSynchronize(g->stream), "group sync");
 }
 
@@ -530,7 +544,7 @@ uint32_t nb_hip_last_step_breakdown(SimPipeline *s, double *kernel_ms, double *c
     NB_ASSERT(s != nullptr, "NULL pipeline");
     if (kernel_ms) *kernel_ms = 0.0;
     if (comm_ms) *comm_ms = 0.0;
-    if (!s->on_device || !s->timed || s->detail_steps == 0) return 0;
+    if (!s->on_device || (!s->timed && !s->group) || s->detail_steps == 0) return 0;
     use_device();
     ASSERT_HIP(hipStreamSynchronize(s->stream), "stream sync");
     if (s->comm_stream) ASSERT_HIP(hipStreamSynchronize(s->comm_stream), "comm stream sync");

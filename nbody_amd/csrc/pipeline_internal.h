@@ -251,6 +251,7 @@ namespace nbi {
 // ---- step_chain.hip ------------------------------------------------------------------------------------------
 
 constexpr uint32_t CANON_STEPS = 32;  // length of the prebuilt chain of small worlds (see wants_canonical)
+constexpr uint32_t DETAIL_STEPS_MAX = 256;  // steps per call whose kernels / gathers get their own event pairs
 
 void destroy_graph(StepGraph &g);
 nb::LaunchShape resolve_shape(SimPipeline *s);

@@ -495,8 +495,6 @@ void allgather_sources(SimPipeline *s, int buf, hipStream_t st) {
     comm_allgather_f32(s, base, per_rank, st, "source positions");
 }
 
-constexpr uint32_t DETAIL_STEPS_MAX = 256;  // steps per call whose kernels / gathers get their own event pairs
-
 // One sharded step of one rank.  `cs` carries the gather (the comm stream with RCCL; the group stream locally).
 // `detail`: bracket the step's kernels and its gather with event pairs (plain launches only, not under capture).
 void sharded_step(SimPipeline *s, nb::LaunchShape sh, float dt, hipStream_t cs, bool detail) {

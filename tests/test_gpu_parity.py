@@ -272,11 +272,68 @@ def avx_steps(part, m, schedule):
     return state
 
 
-# multi-step chains against the reference AVX stepper, relative to what the steps moved: the stated tolerance
-# (DISPLACEMENT_TOL = 1e-4) up to ten steps; longer chains amplify the summation-order difference (the system is chaotic:
-# SURVEY.md 8c) and get 1e-3 -- still 5x below what switching gravity OFF scores on this metric
-def chain_tol(total_steps):
-    return DISPLACEMENT_TOL if total_steps <= 10 else 1e-3
+def f64_steps(part, m, schedule):
+    """The float64 stepper (terms, sums, state and integrator in double: oracle orc_step_f64) over the same schedule."""
+    state = part
+    for n, dt in schedule:
+        state = ob.step(state, m, dt, n, kind="f64")
+    return state
+
+
+SEGMENT_STEPS = 10   # the stated multi-step tolerance is defined over at most ten steps from an identical state
+
+
+def assert_anchored(got, part, m, schedule, label="", **knobs):
+    """Multi-step anchor of a GPU trajectory of ANY length against the reference CPU path (world.c:99-110,
+    sim_cpu.c:156-194), with float64 as the tie-breaker ("closer to fp64 than the AVX path is, is
+    acceptable") -- no looser bound for long chains and no part of a schedule left out.
+
+    Up to ten steps: `got` itself against the AVX stepper at the stated tolerance (1e-4 of what the steps moved), and no
+    further from the float64 trajectory than 1.5 x the AVX stepper's own distance from it.
+
+    Longer schedules: the N-body system is chaotic (a close encounter in the 333-particle fixture multiplies any
+    difference by ~4 000 between steps 130 and 343: the reference's own AVX build ends 1.8e-3 from the float64 trajectory
+    there, this engine 2.9e-3), so end-to-end distances of two fp32 implementations are O(1) multiples of each other by
+    chance and cannot carry a bound.  Instead the WHOLE schedule is re-walked on a second pipeline in calls of at most ten
+    steps (plain launches; `knobs` select the launch shape the trajectory under test is bit-equal to), and every segment
+    is anchored FROM THE GPU'S OWN STATE at its start: GPU segment vs AVX segment at 1e-4, GPU-f64 <= 1.5 x AVX-f64.  The
+    re-walk must end on `got` bit for bit, which ties the checked segments to the trajectory under test.  The end-to-end
+    distances are printed for the record (pytest -rP)."""
+    total = sum(n for n, _ in schedule)
+
+    def check_segment(end_state, start_state, n, dt, what):
+        avx = ob.step(start_state, m, dt, n)
+        f64 = ob.step(start_state, m, dt, n, kind="f64")
+        d_pair = rel_displacement(end_state, avx, start_state)
+        d_gpu, d_avx = rel_displacement(end_state, f64, start_state), rel_displacement(avx, f64, start_state)
+        assert d_pair <= DISPLACEMENT_TOL, (label, what, d_pair)
+        assert d_gpu <= 1.5 * d_avx + 1e-9, (label, what, d_gpu, d_avx)
+        assert np.array_equal(end_state[:, 6:8], avx[:, 6:8])
+        return d_pair, d_gpu, d_avx
+
+    if total <= SEGMENT_STEPS and len(schedule) == 1:
+        d = check_segment(got, part, schedule[0][0], schedule[0][1], f"{total} steps")
+        print(f"[anchor] {label} {total} steps: gpu-avx {d[0]:.3e}  gpu-f64 {d[1]:.3e}  avx-f64 {d[2]:.3e}")
+        return
+    walker = nb.SimPipeline(part.shape[0], m)
+    walker.configure(**dict(dict(graph=0), **knobs))
+    walker.set_data(part)
+    state, done, worst = part, 0, (0.0, 0.0, 0.0)
+    for n, dt in schedule:
+        left = n
+        while left > 0:
+            k = min(left, SEGMENT_STEPS)
+            walker.update(k, dt)
+            nxt = walker.get_data()
+            d = check_segment(nxt, state, k, dt, f"steps {done}..{done + k} of {total}")
+            worst = tuple(max(a, b) for a, b in zip(worst, d))
+            state, done, left = nxt, done + k, left - k
+    walker.close()
+    assert state.tobytes() == got.tobytes(), (label, "the re-walked schedule does not end on the trajectory under test")
+    f64, avx = f64_steps(part, m, schedule), avx_steps(part, m, schedule)
+    print(f"[anchor] {label} {total} steps in segments of <= {SEGMENT_STEPS}: worst segment gpu-avx {worst[0]:.3e}  gpu-f64 {worst[1]:.3e}  "
+          f"avx-f64 {worst[2]:.3e}; end to end (chaotic, not asserted): gpu-f64 {rel_displacement(got, f64, part):.3e}  "
+          f"avx-f64 {rel_displacement(avx, f64, part):.3e}  gpu-avx {rel_displacement(got, avx, part):.3e}")
 
 
 @pytest.mark.parametrize("n_steps", [1, 2, 3, 7, 64, 65, 130])
@@ -286,9 +343,7 @@ def test_graph_chain_equals_plain_launches(golden, n_steps):
     b = run(part, m, n_steps, 0.01, graph=0)
     assert a.tobytes() == b.tobytes()
     # ... and both are the reference's trajectory, not merely each other's
-    want = avx_steps(part, m, [(n_steps, 0.01)])
-    assert rel_displacement(a, want, part) <= chain_tol(n_steps), rel_displacement(a, want, part)
-    assert np.array_equal(a[:, 6:8], want[:, 6:8])
+    assert_anchored(a, part, m, [(n_steps, 0.01)], "graph chain")
 
 
 @pytest.mark.parametrize("graph", [1, 2])
@@ -309,8 +364,9 @@ def test_split_calls_and_odd_phases(golden, graph):
     assert got.tobytes() == want.tobytes()
     assert stats["cached"] == (8 if graph == 1 else 1)   # always: one per (length, phase), capped at 8; auto: the canonical one
     assert stats["dt_uploads"] == 1
-    # (343 steps in all: too long a trajectory to hold against the AVX stepper -- 2e-3 on the displacement metric, chaos,
-    # not error; the first calls of the same schedule are short enough)
+    # the WHOLE 343-step schedule, call by call, against the reference stepper with float64 as the tie-break -- and its
+    # first calls (7 steps) at the stated tolerance
+    assert_anchored(got, part, m, [(n, 0.01) for n in calls], f"split calls graph={graph}")
     head = nb.SimPipeline(333, m)
     head.configure(graph=graph)
     head.set_data(part)
@@ -318,7 +374,7 @@ def test_split_calls_and_odd_phases(golden, graph):
         head.update(n, 0.01)
     early = head.get_data()
     head.close()
-    assert rel_displacement(early, avx_steps(part, m, [(n, 0.01) for n in calls[:3]]), part) <= DISPLACEMENT_TOL
+    assert_anchored(early, part, m, [(n, 0.01) for n in calls[:3]], "split calls, first three")
 
 
 @pytest.mark.parametrize("graph", [1, 2])
@@ -344,8 +400,7 @@ def test_dt_change_patches_the_cached_chain(golden, graph):
     ref.close()
     assert got.tobytes() == want.tobytes()
     # the dt the chain read from device memory is the dt the reference path was given, call by call
-    avx = avx_steps(part, m, [(n, dt) for dt in (0.01, 0.005, 0.01, 0.0025)])
-    assert rel_displacement(got, avx, part) <= chain_tol(4 * n), rel_displacement(got, avx, part)
+    assert_anchored(got, part, m, [(n, dt) for dt in (0.01, 0.005, 0.01, 0.0025)], f"dt change graph={graph}")
     wrong = avx_steps(part, m, [(n, 0.01)] * 4)          # had the chain kept its first dt, it would be here
     assert rel_displacement(got, wrong, part) > 0.1
 
@@ -425,8 +480,7 @@ def test_fused_chain_equals_plain_launches(n, n_steps):
     want = run(part, m, n_steps, 0.01, fused_chain=0, graph=0, **matched_shape(n))
     assert got.tobytes() == want.tobytes()
     assert got.tobytes() == run(part, m, n_steps, 0.01, fused_chain=0, graph=1, **matched_shape(n)).tobytes()
-    avx = avx_steps(part, m, [(n_steps, 0.01)])
-    assert rel_displacement(got, avx, part) <= chain_tol(n_steps), rel_displacement(got, avx, part)
+    assert_anchored(got, part, m, [(n_steps, 0.01)], f"fused chain N={n}", fused_chain=0, **matched_shape(n))
 
 
 def test_fused_chain_auto_policy_and_split_calls():
@@ -1395,13 +1449,23 @@ def test_reference_world_c_drives_our_hip_pipeline(golden):
 
 
 def test_nbody_bench_gpu_column():
+    """nbody-bench --gpu: the GPU column alone (reference src/bench.c:41-74 with --gpu), and -- with --verify 5 -- what that
+    column computed: 5 steps of UpdateWorld_GPU against 5 steps of UpdateWorld_CPU per row, printed and asserted."""
+    import re
     exe = os.path.join(nb.LIB_DIR, "nbody-bench")
-    r = subprocess.run([exe, "--gpu", "--n", "4000", "--n", "20000", "--steps", "10", "--warmup", "2", "--dt", "0.01"],
+    r = subprocess.run([exe, "--gpu", "--n", "4000", "--n", "20000", "--steps", "10", "--warmup", "2", "--dt", "0.01", "--verify", "5"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     rows = [l.split() for l in r.stdout.strip().splitlines()]
     assert rows[0][:2] == ["N", "GPU"] and [x[0] for x in rows[1:]] == ["4000", "20000"]
     assert all(float(x[2]) > 1e9 for x in rows[1:])
+    # us/step x interactions/s = N x M of the row: the two printed figures describe the same run
+    for x, n in zip(rows[1:], (4000, 20000)):
+        pairs = float(x[1]) * 1e-6 * float(x[2])
+        assert 0.3 * n * n <= pairs <= 0.7 * n * n, (x, pairs)      # M ~ N / 2 with galaxy.h ICs
+    devs = [float(v) for v in re.findall(r"GPU vs CPU rel_displacement ([0-9.e+-]+)", r.stderr)]
+    assert len(devs) == 2 and all(d <= 1e-5 for d in devs), r.stderr      # stated tolerance 1e-4; observed ~1e-6
+    assert r.stderr.count("mass/radius equal yes") == 2
 
 
 def test_nbody_bench_verify_column_compares_gpu_with_the_cpu_path():

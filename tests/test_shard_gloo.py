@@ -68,6 +68,78 @@ def test_bench_multi_rank_control_flow_dry_run(world, rendezvous):
     assert out["roofline"]["traffic"] is None and "traffic_note" in out["roofline"]
 
 
+def _one_json_line(stdout):
+    import json
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_started_bare_spawns_its_own_ranks(world):
+    """`python bench.py --gpus N` with no launcher around it (the shape of the driver's N = 1 command, and of the reference
+    harness: one plain process, src/bench.c:41-74): the process stays GPU-free, starts N fresh rank processes itself, relays
+    rank 0's one line and says on it how the ranks came to be."""
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["OMP_NUM_THREADS"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
+                        "--particles", "65536", "--extra-particles", "131072", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    out = _one_json_line(r.stdout)
+    assert out["n_gpus"] == world and out["self_check"]["ranks_agree"] is True
+    assert out["launch"]["mode"].startswith("bare") and len(out["launch"]["attempts"]) == 1
+    assert out["launch"]["attempts"][0] == {"transport": "rccl", "child_rcs": [0] * world,
+                                            "seconds": out["launch"]["attempts"][0]["seconds"]}
+    assert "transport_fallback" not in out and out["transport"].startswith("rccl")
+
+
+@pytest.mark.parametrize("launcher", ["bare", "torchrun"])
+def test_bench_falls_back_to_the_direct_exchange_in_fresh_processes(launcher):
+    """--transport auto (the default): when a rank of the RCCL attempt leaves before the headline is in hand -- rehearsed: the
+    last rank exits with 3 right after the rendezvous, what the library's watchdog does when ncclCommInitRank never
+    completes -- the supervisor ends the attempt's other ranks by exact pid, starts a FRESH set of rank processes over the
+    direct exchange and stamps the line.  Same behaviour whether bench.py spawned the ranks itself or
+    torch.distributed.run did (then every rank process is a GPU-free supervisor of one worker)."""
+    root = os.path.dirname(HERE)
+    world = 3
+    tail = [os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--particles", "65536",
+            "--extra-particles", "131072", "--dry-run", "--no-extras", "--rehearse-rccl-failure"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["OMP_NUM_THREADS"] = "2"
+    if launcher == "bare":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", "29677"] + tail
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    out = _one_json_line(r.stdout)
+    first, second = out["launch"]["attempts"]
+    assert first["transport"] == "rccl" and first["child_rcs"][world - 1] == 3 and any(rc != 0 for rc in first["child_rcs"])
+    assert second["transport"] == "direct" and second["child_rcs"] == [0] * world
+    fb = out["transport_fallback"]
+    assert fb["from"] == "rccl" and fb["to"] == "direct" and fb["rc"] == first["child_rcs"] and fb["why"]
+    assert "rc 3" in fb["stderr_tail"] or "exit 3" in fb["stderr_tail"]
+    assert out["transport"].startswith("direct") and out["n_gpus"] == world and out["self_check"]["ranks_agree"] is True
+    assert out["extra_configs"] == []       # --no-extras keeps the self-check and drops the optional legs
+
+
+def test_bench_supervisor_reports_when_no_attempt_delivers():
+    """An explicit --transport rccl has no fallback: the rehearsed failure ends the run with ONE line that says so (value
+    null, the attempt's exit codes) and a non-zero exit code."""
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--particles", "65536",
+                        "--dry-run", "--no-extras", "--rehearse-rccl-failure", "--transport", "rccl"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode != 0
+    out = _one_json_line(r.stdout)
+    assert out["value"] is None and out["error"] and out["launch"]["attempts"][0]["child_rcs"][1] == 3
+    assert len(out["launch"]["attempts"]) == 1 and "transport_fallback" not in out
+
+
 def test_bench_traffic_figure_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     """roofline.traffic comes from a committed PMC profile and must go null (with a note) once the kernel sources no
     longer hash to what was profiled."""
