@@ -414,30 +414,44 @@ def device_cus(device_info):
     return 256
 
 
-def held_clock_fields(clock, per_launch_s, launch_interactions, device_info, achieved_tflops):
+def held_clock_fields(probe, sampled, per_launch_s, launch_interactions, device_info, achieved_tflops):
     """roofline.held_clock_ghz and what follows from it: how many shader cycles one wave-interaction of the TIMED kernel
     took on every SIMD (kernel seconds x held clock x SIMDs / wave-interactions), which fraction of the instruction mix's
-    26-cycle floor that is, and the roofline fraction re-priced at the held clock instead of the nominal 2.4 GHz."""
-    if not clock or "clock_ghz" not in clock or per_launch_s <= 0 or launch_interactions <= 0:
-        return {"held_clock_ghz": None, "clock_probe": clock}
-    cus = device_cus(device_info)
-    simds = 4 * cus
-    ghz = clock["clock_ghz"]
+    26-cycle floor that is, and the roofline fraction re-priced at the held clock instead of the nominal 2.4 GHz.
+    `sampled` (preferred): the clock sampler's reading during a repeat of the same K steps -- the clock the chip holds
+    under the step kernel itself.  `probe`: the separate probe kernel run right after the headline leg; its loop is denser
+    than the step kernel's, so the chip holds a lower clock for it -- kept on the line as the pure-loop reference."""
+    out = {"held_clock_ghz": None, "clock_probe": probe, "clock_sampled": sampled}
+    ghz, source, slowest = None, None, None
+    if sampled and sampled.get("clock_ghz"):
+        per_xcd = [v for v in sampled.get("per_xcd_ghz", []) if v > 0]
+        # every XCD computes an eighth of a launch (the dispatcher deals workgroups round-robin to the XCDs), so the chip's
+        # clock is the mean over the XCDs -- and the launch ends with its slowest XCD
+        ghz = sum(per_xcd) / len(per_xcd) if per_xcd else sampled["clock_ghz"]
+        slowest = min(per_xcd) if per_xcd else None
+        source = ("clock sampler during a repeat of the same K steps (8 one-wave workgroups, one per XCD, stamping s_memtime / "
+                  "s_memrealtime every 0.5 ms on their own stream, outside the headline's timed region); mean of the per-XCD medians")
+    elif probe and probe.get("clock_ghz"):
+        ghz, source = probe["clock_ghz"], "probe kernel right after the headline leg (reads LOW: its loop is denser than the step kernel's)"
+    if ghz is None or per_launch_s <= 0 or launch_interactions <= 0:
+        return out
+    simds = 4 * device_cus(device_info)
     cycles = per_launch_s * ghz * 1e9 * simds / (launch_interactions / 64.0)
-    return {
+    out.update({
         "held_clock_ghz": ghz,
+        "held_clock_source": source,
         "cycles_per_wave_interaction": cycles,
         "frac_of_mix_ceiling": MIX_FLOOR_CYCLES / cycles,
+        "held_clock_ghz_slowest_xcd": slowest,
+        # workgroups are dealt to the XCDs in equal shares, so a launch lasts as long as its slowest XCD needs
+        "cycles_per_wave_interaction_slowest_xcd": cycles * slowest / ghz if slowest else None,
         "frac_at_held_clock": achieved_tflops / (PEAK_FP32_VECTOR_TFLOPS * ghz / NOMINAL_CLOCK_GHZ),
         # one wave-interaction = 14 x 64 counted flops; the peak is 64 flop per cycle and SIMD (157.3e12 / 1024 / 2.4e9)
         "mix_ceiling_frac_at_nominal_clock": FLOP_PER_INTERACTION / MIX_FLOOR_CYCLES,
-        "clock_probe": dict(clock, note="nb_hip_probe_clock right after the timed steps, outside the timed region: a separate kernel "
-                                        "with the step kernels' interaction statement on scalar operands, 8 waves per SIMD on every "
-                                        "CU, ~40 ms; held clock = median over its waves of d(s_memtime) / d(s_memrealtime) x the "
-                                        "reference rate; its own cycles_per_wave_interaction is the pure loop's (no loads, no "
-                                        "epilogue); cycles_per_wave_interaction above = timed kernel seconds x held clock x "
-                                        f"{simds} SIMDs / wave-interactions; floor of this instruction mix = {MIX_FLOOR_CYCLES:g} cycles"),
-    }
+        "cycles_note": f"cycles_per_wave_interaction = headline kernel seconds per launch x held clock x {simds} SIMDs / wave-interactions "
+                       f"per launch; floor of this instruction mix = {MIX_FLOOR_CYCLES:g} cycles (9 plain fp32 VALU x 2 + v_rsq_f32 x 8)",
+    })
+    return out
 
 
 # ---- deadline guard of the optional legs --------------------------------------------------------------------------------
@@ -817,7 +831,7 @@ def worker_main(args):
             "kernel_ms_per_launch": per_launch_s * 1e3,
             "launches": launches,
             "finish_launches": finish_launches,
-            **held_clock_fields(clock, per_launch_s, launch_interactions, info, achieved_tflops),
+            **held_clock_fields(clock, None, per_launch_s, launch_interactions, info, achieved_tflops),
             "kernel_ms_note": ("HIP events on the launch stream around the whole chain / step-kernel launches"
                                + ("; each interval also holds one O(N) finish kernel (~9 us at 2^20) per step launch"
                                   if finish_launches else "")
@@ -998,6 +1012,21 @@ def worker_main(args):
     elif not sharded and not args.no_extras and not args.dry_run:
         # same K steps twice more (run-to-run spread), then the LDS-tile route of the north star on the same chain
         put("repeat_ms_per_step", [timed_leg(sim, args.steps, 0) / args.steps * 1e3 for _ in range(2)])
+        if not args.no_clock_probe and rank == 0:
+            # the clock the chip holds UNDER THE STEP KERNEL: the same K steps once more with the sampler running beside them
+            try:
+                nb.clock_sampler_begin(0.5, 3.0 * elapsed * 1e3 + 500.0)
+                e_clk = timed_leg(sim, args.steps, 0)
+                clk_ms, clk_launches = sim.last_step_ms()
+                sampled = nb.clock_sampler_end()
+                clk_s = clk_ms * 1e-3 / max(clk_launches, 1)
+                sampled["leg"] = {"ms_per_step": e_clk / args.steps * 1e3, "kernel_ms_per_launch": clk_s * 1e3,
+                                  "cycles_per_wave_interaction": clk_s * sampled["clock_ghz"] * 1e9 * 4 * device_cus(info)
+                                  / (launch_interactions / 64.0) if sampled.get("clock_ghz") else None}
+                with out_lock:
+                    out["roofline"].update(held_clock_fields(clock, sampled, per_launch_s, launch_interactions, info, achieved_tflops))
+            except Exception as e:  # pragma: no cover - diagnostic only
+                put("clock_sampler_error", str(e))
         sim.configure(variant=0)
         e_lds = timed_leg(sim, args.steps, 2)
         lds_ms, lds_launches = sim.last_step_ms()
@@ -1341,8 +1370,9 @@ def supervise(args, argv):
     its error convention with abort()), a self-check that fails -- is followed, with --transport auto, by a SECOND attempt in
     fresh processes over the direct exchange; the line then carries "transport_fallback".  Nothing is ever retried or
     re-executed inside a process that has touched the GPU; stragglers are ended by exact pid.
-    Exit code: 0 when a complete headline (with a passing self-check) was written, whatever optional legs did afterwards --
-    their fate is on the line ("extras_aborted", launch.attempts[].child_rcs); otherwise the worst child code."""
+    Exit code: what the ranks of the LAST attempt left with -- 0 only when every one of them did; a run whose optional leg
+    stalled (4) or aborted (6) after the headline still writes the complete line ("extras_aborted",
+    launch.attempts[].child_rcs) and still does not report success."""
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ
     if under_launcher:
         my_rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -1426,8 +1456,10 @@ def supervise(args, argv):
     if sup is not None:
         sup.barrier()
         sup.close()
+    last = [rc for rc in attempts[-1]["child_rcs"] if rc not in (0, RUNNING)]
+    code = (min(abs(last[0]), 255) or 1) if last else 0      # the worst the final attempt's ranks left with; 0 only when all did
     if my_rank != 0:
-        return 0 if verdict else 1
+        return code if verdict else (code or 1)
     launch = {"mode": mode, "attempts": attempts}
     if verdict:
         line["launch"] = launch
@@ -1436,14 +1468,13 @@ def supervise(args, argv):
             line["transport_fallback"] = {"from": first["transport"], "to": attempts[-1]["transport"], "rc": first["child_rcs"],
                                           "why": first.get("why_not"), "stderr_tail": first.get("stderr_tail", "")[-600:]}
         print(json.dumps(line), flush=True)
-        return 0
+        return code
     # no complete headline from any attempt: still one line, saying so
     partial = line if isinstance(line, dict) else {}
     partial.update({"metric": partial.get("metric", "particle-pair interactions/sec at N=2^20"), "value": partial.get("value"),
                     "unit": "interactions/s", "n_gpus": world, "error": why, "launch": launch})
     print(json.dumps(partial), flush=True)
-    worst = [rc for a in attempts for rc in a["child_rcs"] if rc not in (0, RUNNING)]
-    return (abs(worst[0]) if worst else 1) or 1
+    return code or 1
 
 
 def main(argv=None):

@@ -141,13 +141,29 @@ int nb_hip_runtime_version(void);
  * Runs a separate probe kernel -- the interaction statement of the step kernels on scalar source operands, two
  * receivers per lane, 1024-thread workgroups filling every SIMD with 8 waves, no memory traffic in the loop -- for about
  * target_ms milliseconds; every wave stamps s_memtime (shader cycles) and s_memrealtime (constant reference clock) around
- * its loop.  *clock_ghz = median over the waves of d(memtime) / d(memrealtime) x the reference rate (min / max beside
- * it); *cycles_per_wave_interaction = the median wave's shader cycles per interaction it issued, divided by the 8 waves
- * that share a SIMD (26 = the floor of this instruction mix: 9 plain fp32 VALU at 2 cycles + one v_rsq_f32 at 8).  The
- * product kernels carry no stamps.  Any out pointer may be NULL.  Returns the number of waves that reported.
+ * its loop.  *clock_ghz = d(memtime) / d(memrealtime) x the reference rate, median over the waves that spanned the whole
+ * loop (a SIMD favours its oldest wave: the others finish early; min / max over all waves beside it);
+ * *cycles_per_wave_interaction = the longest wave's shader cycles / 8 waves per SIMD / interactions one wave issued
+ * (26 = the floor of this instruction mix: 9 plain fp32 VALU at 2 cycles + one v_rsq_f32 at 8).  The product kernels carry
+ * no stamps.  Any out pointer may be NULL.  Returns the number of waves that reported.
  */
 int nb_hip_probe_clock(double target_ms, double *clock_ghz, double *clock_ghz_min, double *clock_ghz_max,
                        double *cycles_per_wave_interaction, double *elapsed_ms);
+
+/*
+ * Measurement aid: the shader clock WHILE other work runs.  begin launches 8 one-wave workgroups (one per XCD) on their
+ * own stream that stamp s_memtime / s_memrealtime every period_ms and sleep in between -- 8 of the chip's 8192 wave slots,
+ * a few scalar instructions per period -- until end is called or max_ms has passed (every wave leaves by itself then).
+ * end stops them and reports, over all sampled intervals: median / min / max clock in GHz, the median per XCD
+ * (per_xcd_ghz8[8], 0 where no wave sat), the mean clock of each tenth of the sampled span as one wave saw it (profile10[10]) and
+ * the span in milliseconds.  Intervals in which a counter did not move forward by a sane amount are dropped and counted
+ * (*dropped_intervals).  Returns the number of intervals kept.  Any out pointer may be NULL.  One sampler per process.
+ * bench.py brackets a repeat of the headline leg with it (roofline.held_clock_ghz): the probe above loads the chip with a
+ * denser loop than the step kernel's and therefore reads a lower clock than the step kernel holds.
+ */
+int nb_hip_clock_sampler_begin(double period_ms, double max_ms);
+int nb_hip_clock_sampler_end(double *clock_ghz, double *clock_ghz_min, double *clock_ghz_max, double *per_xcd_ghz8,
+                             double *profile10, double *span_ms, uint32_t *dropped_intervals);
 
 /*
  * Optional: tell the pipeline which long-lived host array Set/GetSimulationData will be called with (the World's

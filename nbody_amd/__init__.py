@@ -66,6 +66,8 @@ HIP_API = {
     "nb_hip_graph_stats": (C.c_uint32, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "nb_hip_runtime_version": (C.c_int, []),
     "nb_hip_probe_clock": (C.c_int, [C.c_double] + [C.POINTER(C.c_double)] * 5),
+    "nb_hip_clock_sampler_begin": (C.c_int, [C.c_double, C.c_double]),
+    "nb_hip_clock_sampler_end": (C.c_int, [C.POINTER(C.c_double)] * 6 + [C.POINTER(C.c_uint32)]),
     "nb_hip_launch_unit": (C.c_int, [C.c_void_p]),
     "nb_hip_last_fused_steps": (C.c_uint32, [C.c_void_p]),
     "nb_hip_launch_lanes": (C.c_int, [C.c_void_p]),
@@ -171,6 +173,20 @@ def probe_clock(target_ms=40.0):
     waves = hip_lib().nb_hip_probe_clock(float(target_ms), *[C.byref(x) for x in v])
     return {"clock_ghz": v[0].value, "clock_ghz_min": v[1].value, "clock_ghz_max": v[2].value,
             "cycles_per_wave_interaction": v[3].value, "elapsed_ms": v[4].value, "waves": int(waves)}
+
+
+def clock_sampler_begin(period_ms=0.5, max_ms=6000.0):
+    """include/nbody_hip.h nb_hip_clock_sampler_begin: sample the shader clock while other kernels run."""
+    return int(hip_lib().nb_hip_clock_sampler_begin(float(period_ms), float(max_ms)))
+
+
+def clock_sampler_end():
+    ghz, lo, hi, span = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+    per_xcd, profile = (C.c_double * 8)(), (C.c_double * 10)()
+    dropped = C.c_uint32(0)
+    n = hip_lib().nb_hip_clock_sampler_end(C.byref(ghz), C.byref(lo), C.byref(hi), per_xcd, profile, C.byref(span), C.byref(dropped))
+    return {"clock_ghz": ghz.value, "clock_ghz_min": lo.value, "clock_ghz_max": hi.value, "per_xcd_ghz": [float(v) for v in per_xcd],
+            "profile_ghz": [float(v) for v in profile], "span_ms": span.value, "intervals": int(n), "dropped_intervals": int(dropped.value)}
 
 
 def shard_plan(total_len, mass_len, rank, nranks):

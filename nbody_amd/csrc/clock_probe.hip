@@ -7,9 +7,10 @@
 // interaction_asm.h on scalar (SGPR) source operands, eight sources per group -- and loops over the same eight sources
 // `iters` times, so the loop is the step kernel's inner loop minus its scalar loads.  Every wave stamps s_memtime (shader
 // cycles) and s_memrealtime (the constant 100 MHz reference) once before and once after the loop:
-//     held clock              = d(memtime) / d(memrealtime) x reference rate
-//     cycles per wave-interaction = d(memtime) / (waves per SIMD) / (interactions the wave issued)
-// A caller that runs it right after a timed leg reads the clock the chip held for that leg's kind of work.
+//     held clock              = d(memtime) / d(memrealtime) x reference rate      (waves that spanned the whole loop)
+//     cycles per wave-interaction = longest d(memtime) / (waves per SIMD) / (interactions one wave issued)
+// The clock it reads is the clock the chip holds FOR THIS LOOP, which is denser than the step kernel's (no scalar loads,
+// no epilogue) and therefore a little lower; the sampler below reads the clock under the step kernel itself.
 #include "interaction_asm.h"
 #include "pipeline_internal.h"
 
@@ -74,7 +75,167 @@ __global__ __launch_bounds__(64 * PROBE_WAVES, 8) void clock_probe_kernel(const 
     if (ax0 + ay0 + ax1 + ay1 == 12345.678f) sink[tid] = ax0;
 }
 
+// ---- the clock sampler: the shader clock WHILE other kernels run ------------------------------------------------------
+//
+// The probe above loads the chip with its own loop, and a denser loop than the step kernel's (no scalar loads, no
+// epilogue) makes the chip hold a LOWER clock than the step kernel does (measured: 2.23 GHz against 2.30).  What a timed leg
+// needs is the clock the chip held during that leg.  So: a handful of one-wave workgroups (the dispatcher deals
+// consecutive workgroups to consecutive XCDs: one per XCD) that do nothing but stamp s_memtime / s_memrealtime once per
+// period and sleep in between, launched on their own stream BEFORE the leg and told to leave after it through a word of
+// page-locked host memory.  They hold 8 of the chip's 8192 wave slots and issue a few scalar instructions per period.  Every
+// wave leaves by itself after max_samples periods (a bounded kernel: no wave can outlive the stop word by more than one
+// period, nor the bound without it).
+struct SamplerPair {
+    uint64_t cycles, ref;
+};
+
+__global__ __launch_bounds__(64) void clock_sampler_kernel(SamplerPair *__restrict__ out, uint32_t *__restrict__ count, uint32_t *__restrict__ xcc,
+                                                           const uint32_t *stop, uint32_t max_samples, uint32_t period_ticks) {
+    const bool writer = threadIdx.x == 0;
+    uint32_t id = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    uint32_t i = 0;
+    while (i < max_samples) {
+        const uint64_t c = __builtin_amdgcn_s_memtime();
+        const uint64_t t = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (writer) {
+            SamplerPair v;
+            v.cycles = c;
+            v.ref = t;
+            out[(size_t)blockIdx.x * max_samples + i] = v;
+        }
+        i++;
+        if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
+        uint64_t now = t;
+        while (now - t < period_ticks) {
+            __builtin_amdgcn_s_sleep(127);
+            now = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+        }
+    }
+    if (writer) {
+        count[blockIdx.x] = i;
+        xcc[blockIdx.x] = id & 0xfu;
+    }
+}
+
+constexpr int SAMPLER_WAVES = 8;
+
+struct Sampler {
+    bool running = false;
+    hipStream_t stream = nullptr;
+    SamplerPair *out = nullptr;
+    uint32_t *count = nullptr, *xcc = nullptr;
+    uint32_t *stop = nullptr;   // page-locked host word, read by the waves with system scope
+    uint32_t max_samples = 0;
+    int wall_khz = 100000;
+} g_sampler;
+
 }  // namespace
+
+extern "C" int nb_hip_clock_sampler_begin(double period_ms, double max_ms) {
+    using namespace nbi;
+    use_device();
+    Sampler &S = g_sampler;
+    NB_ASSERT(!S.running, "clock sampler already running");
+    NB_ASSERT(period_ms >= 0.05 && max_ms >= period_ms && max_ms <= 20000.0, "sampler period %g ms, bound %g ms", period_ms, max_ms);
+    if (hipDeviceGetAttribute(&S.wall_khz, hipDeviceAttributeWallClockRate, g_dev.ordinal) != hipSuccess || S.wall_khz <= 0) {
+        (void)hipGetLastError();
+        S.wall_khz = 100000;
+    }
+    S.max_samples = (uint32_t)(max_ms / period_ms) + 2;
+    S.out = dev_alloc<SamplerPair>((size_t)SAMPLER_WAVES * S.max_samples);
+    S.count = dev_alloc<uint32_t>(SAMPLER_WAVES);
+    S.xcc = dev_alloc<uint32_t>(SAMPLER_WAVES);
+    ASSERT_HIP(hipHostMalloc(reinterpret_cast<void **>(&S.stop), sizeof(uint32_t), hipHostMallocDefault), "sampler stop word");
+    *S.stop = 0u;
+    ASSERT_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking), "sampler stream");
+    ASSERT_HIP(hipMemsetAsync(S.count, 0, SAMPLER_WAVES * sizeof(uint32_t), S.stream), "sampler counts");
+    const uint32_t period_ticks = (uint32_t)(period_ms * (double)S.wall_khz);
+    hipLaunchKernelGGL(clock_sampler_kernel, dim3(SAMPLER_WAVES), dim3(64), 0, S.stream, S.out, S.count, S.xcc, S.stop, S.max_samples, period_ticks);
+    ASSERT_HIP(hipGetLastError(), "clock sampler launch");
+    S.running = true;
+    return SAMPLER_WAVES;
+}
+
+extern "C" int nb_hip_clock_sampler_end(double *clock_ghz, double *clock_ghz_min, double *clock_ghz_max, double *per_xcd_ghz8,
+                                        double *profile10, double *span_ms, uint32_t *dropped_intervals) {
+    using namespace nbi;
+    use_device();
+    Sampler &S = g_sampler;
+    NB_ASSERT(S.running, "clock sampler not running");
+    __atomic_store_n(S.stop, 1u, __ATOMIC_RELEASE);
+    ASSERT_HIP(hipStreamSynchronize(S.stream), "sampler sync");
+    const size_t stride = S.max_samples;
+    const double khz = (double)S.wall_khz;   // ticks of s_memrealtime per millisecond
+    std::vector<SamplerPair> host((size_t)SAMPLER_WAVES * stride);
+    uint32_t count[SAMPLER_WAVES], xcc[SAMPLER_WAVES];
+    ASSERT_HIP(hipMemcpy(host.data(), S.out, host.size() * sizeof(SamplerPair), hipMemcpyDeviceToHost), "sampler stamps");
+    ASSERT_HIP(hipMemcpy(count, S.count, sizeof count, hipMemcpyDeviceToHost), "sampler counts");
+    ASSERT_HIP(hipMemcpy(xcc, S.xcc, sizeof xcc, hipMemcpyDeviceToHost), "sampler xcc ids");
+    ASSERT_HIP(hipStreamDestroy(S.stream), "sampler stream");
+    dev_free(S.out);
+    dev_free(S.count);
+    dev_free(S.xcc);
+    ASSERT_HIP(hipHostFree(S.stop), "sampler stop word");
+    S = Sampler();
+
+    std::vector<double> all, by_xcd[8];
+    double span = 0.0;
+    uint32_t dropped = 0;
+    if (per_xcd_ghz8)
+        for (int x = 0; x < 8; x++) per_xcd_ghz8[x] = 0.0;
+    std::vector<double> first_wave;   // interval clocks of the longest-lived wave, in time order, for the profile
+    for (int w = 0; w < SAMPLER_WAVES; w++) {
+        const SamplerPair *p = host.data() + (size_t)w * stride;
+        std::vector<double> mine;
+        for (uint32_t i = 1; i < count[w] && i < stride; i++) {
+            // an interval counts when both counters moved forward by a sane amount (under 5 GHz, under a second): a stamp
+            // pair that straddles a counter hiccup is dropped and counted, not averaged in
+            const uint64_t dr = p[i].ref - p[i - 1].ref, dc = p[i].cycles - p[i - 1].cycles;
+            if (dr == 0 || dr > (uint64_t)(1000.0 * khz) || dc == 0 || (double)dc > 50.0 * (double)dr) {
+                dropped++;
+                continue;
+            }
+            mine.push_back((double)dc / (double)dr * khz * 1.0e-6);   // cycles per ms -> GHz
+        }
+        if (count[w] >= 2) span = std::max(span, (double)(p[count[w] - 1].ref - p[0].ref) / khz);
+        all.insert(all.end(), mine.begin(), mine.end());
+        auto &bucket = by_xcd[xcc[w] & 7u];
+        bucket.insert(bucket.end(), mine.begin(), mine.end());
+        if (mine.size() > first_wave.size()) first_wave = mine;
+    }
+    if (dropped_intervals) *dropped_intervals = dropped;
+    if (all.empty()) {
+        if (clock_ghz) *clock_ghz = 0.0;
+        if (clock_ghz_min) *clock_ghz_min = 0.0;
+        if (clock_ghz_max) *clock_ghz_max = 0.0;
+        if (span_ms) *span_ms = span;
+        return 0;
+    }
+    std::sort(all.begin(), all.end());
+    if (clock_ghz) *clock_ghz = all[all.size() / 2];
+    if (clock_ghz_min) *clock_ghz_min = all.front();
+    if (clock_ghz_max) *clock_ghz_max = all.back();
+    if (per_xcd_ghz8)
+        for (int x = 0; x < 8; x++)
+            if (!by_xcd[x].empty()) {
+                std::sort(by_xcd[x].begin(), by_xcd[x].end());
+                per_xcd_ghz8[x] = by_xcd[x][by_xcd[x].size() / 2];
+            }
+    if (profile10)
+        for (int q = 0; q < 10; q++) {
+            // mean clock of the q-th tenth of the sampled span, as one wave saw it
+            const size_t lo = first_wave.size() * (size_t)q / 10, hi = std::max(lo + 1, first_wave.size() * (size_t)(q + 1) / 10);
+            double sum = 0.0;
+            size_t n = 0;
+            for (size_t i = lo; i < hi && i < first_wave.size(); i++, n++) sum += first_wave[i];
+            profile10[q] = n ? sum / (double)n : 0.0;
+        }
+    if (span_ms) *span_ms = span;
+    return (int)all.size();
+}
 
 extern "C" int nb_hip_probe_clock(double target_ms, double *clock_ghz, double *clock_ghz_min, double *clock_ghz_max,
                                   double *cycles_per_wave_interaction, double *elapsed_ms) {
@@ -123,21 +284,26 @@ extern "C" int nb_hip_probe_clock(double target_ms, double *clock_ghz, double *c
     dev_free(sink);
     dev_free(stamps);
 
-    std::vector<double> ghz, cyc;
-    ghz.reserve(waves);
-    cyc.reserve(waves);
+    // The SIMD's arbiter favours its oldest wave, so the eight waves of a SIMD do not finish together: the oldest leaves
+    // after about an eighth of the launch, the youngest spans all of it (measured: median lifetime 0.56 of the launch).
+    // The waves that lived (nearly) as long as the longest one saw the whole loop: their clock is the launch's clock, and
+    // the longest lifetime is the SIMDs' busy time, in which 8 waves issued iters x 16 wave-interactions each.
+    uint64_t longest = 0;
+    for (const ProbeStamp &s : host) longest = std::max(longest, s.cycles);
+    std::vector<double> ghz, ghz_all;
     for (const ProbeStamp &s : host) {
         if (s.ref == 0) continue;
-        ghz.push_back((double)s.cycles / (double)s.ref * (double)wall_khz * 1.0e-6);
-        cyc.push_back((double)s.cycles / PROBE_WAVES_PER_SIMD / ((double)iters * 16.0));
+        const double g = (double)s.cycles / (double)s.ref * (double)wall_khz * 1.0e-6;
+        ghz_all.push_back(g);
+        if ((double)s.cycles >= 0.9 * (double)longest) ghz.push_back(g);
     }
     NB_ASSERT(!ghz.empty(), "clock probe: no wave reported a stamp");
     std::sort(ghz.begin(), ghz.end());
-    std::sort(cyc.begin(), cyc.end());
+    std::sort(ghz_all.begin(), ghz_all.end());
     if (clock_ghz) *clock_ghz = ghz[ghz.size() / 2];
-    if (clock_ghz_min) *clock_ghz_min = ghz.front();
-    if (clock_ghz_max) *clock_ghz_max = ghz.back();
-    if (cycles_per_wave_interaction) *cycles_per_wave_interaction = cyc[cyc.size() / 2];
+    if (clock_ghz_min) *clock_ghz_min = ghz_all.front();
+    if (clock_ghz_max) *clock_ghz_max = ghz_all.back();
+    if (cycles_per_wave_interaction) *cycles_per_wave_interaction = (double)longest / PROBE_WAVES_PER_SIMD / ((double)iters * 16.0);
     if (elapsed_ms) *elapsed_ms = (double)ms;
-    return (int)ghz.size();
+    return (int)ghz_all.size();
 }

@@ -1853,3 +1853,46 @@ print("NOT REACHED")
     r = subprocess.run([sys.executable, str(worker), nb.ROOT], capture_output=True, text=True, timeout=300)
     assert r.returncode == 5, (r.returncode, r.stderr[-2000:])
     assert "transport fell over" in r.stderr and "all-gather raised" in r.stderr and "NOT REACHED" not in r.stdout
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# measurement aids: the clock probe and the clock sampler (include/nbody_hip.h; bench.py roofline.held_clock_ghz)
+# ---------------------------------------------------------------------------------------------------------------
+
+def test_clock_probe_reads_a_plausible_clock_and_the_instruction_mix_floor():
+    """nb_hip_probe_clock: the step kernels' interaction statement alone, 8 waves per SIMD on every CU.  The clock must be a
+    gfx950 shader clock (between 1.2 and the 2.4 GHz maximum, MI355X_MICROARCH.md) and the loop must run at the floor of
+    its instruction mix: 26 cycles per wave-interaction (9 plain fp32 VALU x 2 + one v_rsq_f32 x 8), within ramp and
+    arbitration losses -- which is what DESIGN.md prices the step kernel against."""
+    p = nb.probe_clock(20.0)
+    assert p["waves"] == 8192, p
+    assert 1.2 <= p["clock_ghz_min"] <= p["clock_ghz"] <= p["clock_ghz_max"] <= 2.45, p
+    assert 25.9 <= p["cycles_per_wave_interaction"] <= 29.0, p
+    assert 10.0 <= p["elapsed_ms"] <= 60.0, p
+
+
+def test_clock_sampler_runs_beside_the_step_kernels_without_touching_their_results():
+    """nb_hip_clock_sampler_*: eight one-wave workgroups stamp the shader clock while a step chain runs on the pipeline's own
+    stream.  The chain's results are bit-identical with and without the sampler, the sampler covers the chain's span, sits
+    on several XCDs, and leaves by itself when its bound passes even if nobody stops it."""
+    n = 65536
+    _, part, m = bench_universe(n)
+    want = run(part, m, 20, 0.01)
+    sim = nb.SimPipeline(n, m)
+    sim.set_data(part)
+    assert nb.clock_sampler_begin(0.2, 4000.0) == 8
+    sim.update(20, 0.01)
+    got = sim.get_data()
+    s = nb.clock_sampler_end()
+    sim.close()
+    assert got.tobytes() == want.tobytes()
+    assert s["intervals"] >= 8 and 1.0 <= s["clock_ghz_min"] <= s["clock_ghz"] <= s["clock_ghz_max"] <= 2.45, s
+    assert s["span_ms"] >= 5.0 and sum(1 for v in s["per_xcd_ghz"] if v > 0) >= 2, s
+    assert all(1.0 <= v <= 2.45 for v in s["profile_ghz"]), s
+    # bounded: never stopped from the host, the waves leave after max_ms by themselves (end() then only collects)
+    import time
+    nb.clock_sampler_begin(0.2, 100.0)
+    time.sleep(0.5)
+    t0 = time.perf_counter()
+    late = nb.clock_sampler_end()
+    assert time.perf_counter() - t0 < 0.2 and 80.0 <= late["span_ms"] <= 140.0, late
