@@ -130,9 +130,6 @@ int nb_hip_comm_info(const SimPipeline *sim, int *nranks, int *rank, int *device
  * sim_gpu.c:268-284, so a changed dt never rebuilds or patches a cached chain). */
 uint32_t nb_hip_graph_stats(const SimPipeline *sim, uint32_t *dt_uploads);
 
-/* The source-slice granule ("unit" knob) the last step launch used. */
-int nb_hip_launch_unit(const SimPipeline *sim);
-
 /* hipRuntimeGetVersion() of the HIP runtime this process actually bound (0 when it cannot be asked). */
 int nb_hip_runtime_version(void);
 
@@ -170,84 +167,42 @@ int nb_hip_clock_sampler_end(double *clock_ghz, double *clock_ghz_min, double *c
  * particle array).  It is page-locked (hipHostRegister) when the pipeline first touches the GPU and released in
  * DestroySimPipeline, so the hand-over runs at PCIe speed instead of through pageable memory.  The array must stay
  * allocated until DestroySimPipeline or until this is called again (array = NULL forgets it).  Set/Get with any
- * other pointer keep working unchanged.  See the "readback" knob for what else the pipeline may do with it.
+ * other pointer keep working unchanged.  In a frame loop (every blocking update followed by a Get into this array,
+ * reference src/main.c:157-163,237) the pipeline appends the read-back to the update's own submission.
  */
 void nb_hip_note_host_array(SimPipeline *sim, void *array, uint64_t bytes);
 
 /*
- * Tuning knobs.  key is one of:
- *   "variant"   0 = wave-private LDS tiles, 1 = scalar-cache (SMEM) source broadcast (default: 8 % faster at N = 2^20,
- *               every bench.py line times both: roofline.alt_lds)
- *   "k"         receivers per lane: 0 = auto, else 1 or 2 (4 only in TUNING=1 builds)
- *   "w"         waves (source slices) per workgroup: 0 = auto (4, 8 or 16), else 1, 4, 8 or 16 (2 only in TUNING=1
- *               builds); w = 1 makes the summation order independent of the launch geometry
- *   "split"     workgroups per receiver tile, each over 1/split of the sources (a second small kernel adds
- *               the parts and integrates): 0 = auto (fills the chip / lands on a round boundary), else 1..16
- *   "unit"      granule of the source slicing: a wave's slice is a whole number of `unit` sources.  0 = auto (64; 32, 16
- *               or 8 for latency-bound launches whose source parts hold fewer 64-source chunks than a workgroup has
- *               waves), else 8, 16, 32 or 64.  The LDS route ("variant" 0) always uses 64; the two routes give the
- *               same bits whenever the granule is 64
- *   "passes"    launches per step over consecutive source sub-ranges, chained through acc[]: 0 = auto (each
- *               pass's sources fit one XCD's L2, so they are fetched once per pass instead of once per round:
- *               23x less memory-side traffic at N = 2^20, same speed), else 1..64
+ * Run-time knobs a user of the reference harness needs.  key is one of:
+ *   "variant"   how the wave-uniform sources reach the VALU: 1 (default) = through the scalar cache as SGPR operands,
+ *               0 = wave-private LDS tiles (north star's design; bit-identical results, 8 % slower at N = 2^20: every
+ *               bench.py line times both, roofline.alt_lds)
  *   "graph"     how PerformSimUpdate(n > 1) runs its chain: 0 = plain stream launches; 1 = always as a hipGraph, built on
  *               first use and cached per (length, ping-pong phase); 2 (default) = auto: calls shorter than 16 steps are
- *               plain launches (a graph launch costs the host ~12 us more than a few plain launches).  Longer calls on
- *               small worlds (N x M <= 6e7, about N <= 11 000: steps short enough that a replayed node beats a plain
- *               launch) replay ONE canonical 32-step chain that is built when the data first reaches the device,
- *               with plain launches for the remainder; on larger worlds a chain length runs as plain launches the first
- *               time it is asked for and as a cached hipGraph from the second time on (a replay saves nothing there).
- *               The step size is never baked into a chain: kernels read it from device memory.
- *   "lanes"     lane groups per wave: 2, 4 or 8 = the 64 lanes of a wave are that many groups over the SAME 64 / lanes receivers,
- *               each group walking its own slice of the sources (w x lanes slices per receiver inside one workgroup: the
- *               parallelism of a source split without its second kernel; sources staged through LDS tile by tile, k = 1,
- *               split = 1, unsharded single-pass steps only); 1 = never; 0 (default) = auto: latency-bound launches
- *               (N x M <= 9e6, about N <= 4 000) whose other shape knobs are on auto -- 15-28 % faster there than the best
- *               split shape (profiles/r03_lane_split_scan.txt)
- *   "fused_chain"  worlds that fit ONE 1024-thread workgroup (N <= 512) can run a whole n-step call inside one launch:
- *               positions in LDS, two workgroup barriers per step, no kernel boundary (1.6-1.8 us each, more than such a
- *               step's arithmetic).  2 (default) = auto: calls of 2+ steps while N <= 256 and N x M <= 3.6e4 (beyond that one
- *               compute unit is slower than per-step launches over the whole chip) and the launch shape is on auto; 1 =
- *               whenever the world fits; 0 = never.  Same bits as per-step launches with k = 2, w = 16 / tiles, split = 1,
- *               unit = 8 (tiles = 1, 2, 4 for N <= 128, 256, 512); nb_hip_launch_shape reports that shape
- *   "fused_finish"  split shapes without their second kernel: the workgroup of a receiver tile that arrives LAST adds
- *               the tile's parts (written and read with agent-scope sc1 accesses, one ticket per tile) and integrates, in
- *               the same order and with the same roundings as the finish kernel: same bits, one dependent launch less
- *               per pass.  2 (default) = auto: unsharded steps on the scalar-cache route with N x M >= 4e7 (N >~ 9 000;
- *               below that it loses inside a hipGraph) and at most 200 000 receivers: -0.4 ... -2.3 us per step at
- *               N = 10 000 ... 100 000 (profiles/r04_fused_finish.txt); 1 = whenever the shape has a split and the
- *               route is the scalar cache; 0 = never.  Sharded steps always use the finish kernel
- *   "readback"  when the device state reaches the host array named by nb_hip_note_host_array: 0 = only when
- *               GetSimulationData asks (merge kernel + D2H copy + wait), 1 = at the end of every blocking
- *               PerformSimUpdate (the merge kernel is appended to the update's own submission and stores straight into
- *               the page-locked array; the following GetSimulationData into that array returns at once), 2 (default) =
- *               auto: eager once two updates in a row were each followed by a Get into the noted array (a frame loop:
- *               reference src/main.c:157-163,237), lazy again as soon as an update follows an update.  Between an
- *               eager PerformSimUpdate and the next GetSimulationData the noted array's contents are unspecified (old
- *               or new state); the include/nbody.h surface never exposes that window (GetWorldParticles pulls first).
- *   "zero_copy_upload"  1 (default) = SetSimulationData from the noted, page-locked array lets the split kernel read the
- *               records over PCIe itself (one launch); 0 = DMA copy into device staging, then the kernel
+ *               plain launches; longer calls on small worlds (N x M <= 6e7) replay ONE canonical 32-step chain built when
+ *               the data first reaches the device; on larger worlds a chain length runs as plain launches the first time
+ *               it is asked for and as a cached hipGraph from the second time on.  The step size is never baked into a
+ *               chain: kernels read it from device memory
  *   "timing"    1 = bracket every chain with a HIP event pair so that nb_hip_last_step_ms can answer, 0 (default) =
  *               do not (the two records cost a frame loop 3-7 us per call)
- *   "sharded_graph"  sharded pipelines: 1 = capture the {kernel, all-gather} x n chain into a hipGraph and replay
- *               it (non-overlapped step only); 0 = plain stream launches (default)
- *   "overlap"   sharded pipelines: 1 = split each step into own-shard / remote-shard kernels
- *               with the all-gather in between on a second stream, 0 = gather then one kernel (default)
+ *   "overlap"   sharded pipelines: 1 = split each step into own-shard / remote-shard kernels with the all-gather in
+ *               between on a second stream, 0 = gather then one kernel (default)
+ *   "sharded_graph"  sharded pipelines: 1 = capture the {kernel, all-gather} x n chain into a hipGraph and replay it
+ *               (non-overlapped step only); 0 = plain stream launches (default)
  *               Both are opt-in by policy: per rank a step is O(N*M/P) of kernel against an O(M)
- *               gather -- <= 0.5 % of a step at the BASELINE sizes -- so neither can pay there, RCCL with more than one rank
- *               (and RCCL inside stream capture) has never run here, and every harness times all three modes from one
- *               command so that the first multi-GPU run decides with numbers
+ *               gather, and every harness times all three modes from one command.
+ * The same five can be preset from the environment: NB_HIP_VARIANT, NB_HIP_GRAPH, NB_HIP_OVERLAP, NB_HIP_SHARDED_GRAPH
+ * (+ NB_HIP_FORCE_SHARDED = keep the RCCL path for a single rank, NB_HIP_COMM_TIMEOUT_S = bound of every wait on other
+ * ranks).  Launch-shape and experiment knobs (receivers per lane, waves per workgroup, source split / passes / granule,
+ * lane-split and one-workgroup chains, the fused finish, the frame loop's eager read-back) are NOT part of this ABI: every
+ * one is on "auto", auto is what every published number was measured with, and the knobs that lost every measurement
+ * live on only as test and tooling hooks (nbody_amd/csrc/nbody_hip_tuning.h: nb_hip_tune; their environment variables
+ * exist in TUNING=1 builds only).
  * Returns the previous value; aborts on an unknown key or value.
  */
 int nb_hip_configure(SimPipeline *sim, const char *key, int value);
 
-/* Steps of the last PerformSimUpdate / nb_hip_step_async that ran inside one-workgroup chain launches ("fused_chain"). */
-uint32_t nb_hip_last_fused_steps(const SimPipeline *sim);
-
-/* Lane groups per wave of the last step launch ("lanes" knob): 1, 2, 4 or 8. */
-int nb_hip_launch_lanes(const SimPipeline *sim);
-
-/* What the last step launch actually used (after "auto"): fills k, w, variant, split, workgroups. */
+/* What the last step launch actually used (everything is on auto unless a tuning hook moved it): k, w, variant, split, workgroups. */
 void nb_hip_launch_shape(const SimPipeline *sim, int *k, int *w, int *variant, int *split, uint32_t *workgroups);
 
 /*
@@ -257,20 +212,6 @@ void nb_hip_launch_shape(const SimPipeline *sim, int *k, int *w, int *variant, i
  * minimises rounds * work-per-workgroup, rounds = ceil(workgroups / resident slots).
  */
 void nb_hip_plan_launch(uint32_t n_recv, uint32_t n_src, int compute_units, int *k, int *w, int *split, uint32_t *workgroups);
-
-/*
- * Whether an unsharded step of that size runs as a lane-split launch when every shape knob is on auto ("lanes" knob):
- * returns the lane groups per wave (1 = no: the classic shape nb_hip_plan_launch describes is used) and, through w, the
- * waves per workgroup.  Lane-split steps are ONE kernel (no finish kernel).
- */
-int nb_hip_plan_launch_lanes(uint32_t n_recv, uint32_t n_src, int *w);
-
-/* 1 when an unsharded all-auto step of that size runs its source split WITHOUT the finish kernel ("fused_finish" knob on
- * auto): one kernel per pass instead of two.  Pure host code. */
-int nb_hip_plan_fused_finish(uint32_t n_recv, uint32_t n_src, int compute_units);
-
-/* The source-slice granule ("unit" knob: 64, 32, 16 or 8 sources) the same arithmetic picks for such a launch. */
-int nb_hip_plan_launch_unit(uint32_t n_recv, uint32_t n_src, int compute_units);
 
 /* -- sharded (multi-GPU) pipeline: one process per GPU, N/P receivers each -- */
 

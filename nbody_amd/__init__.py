@@ -68,18 +68,12 @@ HIP_API = {
     "nb_hip_probe_clock": (C.c_int, [C.c_double] + [C.POINTER(C.c_double)] * 5),
     "nb_hip_clock_sampler_begin": (C.c_int, [C.c_double, C.c_double]),
     "nb_hip_clock_sampler_end": (C.c_int, [C.POINTER(C.c_double)] * 6 + [C.POINTER(C.c_uint32)]),
-    "nb_hip_launch_unit": (C.c_int, [C.c_void_p]),
-    "nb_hip_last_fused_steps": (C.c_uint32, [C.c_void_p]),
-    "nb_hip_launch_lanes": (C.c_int, [C.c_void_p]),
     "nb_hip_note_host_array": (None, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "nb_hip_configure": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "nb_hip_launch_shape": (None, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "nb_hip_plan_launch": (None, [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
-    "nb_hip_plan_launch_unit": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int]),
-    "nb_hip_plan_fused_finish": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int]),
-    "nb_hip_plan_launch_lanes": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_int)]),
     "nb_hip_comm_unique_id": (None, [C.c_void_p]),
     "CreateSimPipelineSharded": (C.c_void_p, [WorldData, C.c_int, C.c_int, C.c_void_p]),
     "CreateSimPipelineShardedWith": (C.c_void_p, [WorldData, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]),
@@ -89,6 +83,18 @@ HIP_API = {
     "nb_hip_local_group_step": (None, [C.POINTER(C.c_void_p), C.c_int, C.c_uint32, C.c_float]),
     "nb_hip_version": (C.c_int, []),
 }
+
+# nbody_amd/csrc/nbody_hip_tuning.h: test and tooling hooks, exported by the library but NOT part of the C-ABI
+TUNE_API = {
+    "nb_hip_tune": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "nb_hip_launch_unit": (C.c_int, [C.c_void_p]),
+    "nb_hip_last_fused_steps": (C.c_uint32, [C.c_void_p]),
+    "nb_hip_launch_lanes": (C.c_int, [C.c_void_p]),
+    "nb_hip_plan_launch_unit": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int]),
+    "nb_hip_plan_fused_finish": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int]),
+    "nb_hip_plan_launch_lanes": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_int)]),
+}
+PUBLIC_KNOBS = ("variant", "graph", "timing", "overlap", "sharded_graph")   # nb_hip_configure; everything else is a tuning hook
 
 # include/nbody.h + include/galaxy.h
 NBODY_API = {
@@ -134,7 +140,7 @@ def hip_lib():
         _build_if_missing(HIP_SO)
         if not os.path.exists(HIP_SO):
             raise OSError(f"{HIP_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
-        _hip = _bind(C.CDLL(HIP_SO, mode=C.RTLD_GLOBAL), HIP_API)
+        _hip = _bind(_bind(C.CDLL(HIP_SO, mode=C.RTLD_GLOBAL), HIP_API), TUNE_API)
     return _hip
 
 
@@ -317,8 +323,11 @@ class SimPipeline:
         return int(hip_lib().nb_hip_last_fused_steps(self._h))
 
     def configure(self, **knobs):
+        """The five knobs of include/nbody_hip.h go through nb_hip_configure; anything else is a launch-shape / experiment
+        hook of nbody_hip_tuning.h (nb_hip_tune; aborts on an unknown name like the public call does)."""
         for k, v in knobs.items():
-            hip_lib().nb_hip_configure(self._h, k.encode(), int(v))
+            fn = hip_lib().nb_hip_configure if k in PUBLIC_KNOBS else hip_lib().nb_hip_tune
+            fn(self._h, k.encode(), int(v))
 
     def launch_shape(self):
         k, w, v, sp, g = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_uint32()

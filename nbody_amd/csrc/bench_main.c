@@ -72,6 +72,7 @@
 #include <nbody.h>
 #include <nbody_hip.h>
 
+#include "nbody_hip_tuning.h" /* floor-column planning + the --one-wave hook; not the public ABI */
 #include "rank_page.h"
 
 #define CALIBRATION_N 100000u     /* the last row of the reference's table (bench.c:38): the large-N rate is measured there */
@@ -131,7 +132,7 @@ enum { MODE_PLAIN = 0, MODE_OVERLAP = 1, MODE_GRAPH = 2, MODE_COUNT = 3 };
 static const char *const MODE_NAME[MODE_COUNT] = {"plain", "overlap", "graph"};
 
 typedef struct Options {
-    bool use_cpu, use_gpu, own_rng, transport_shm, transport_ipc, force_sharded, selftest_ranks, verify_given, speedup;
+    bool use_cpu, use_gpu, own_rng, transport_shm, transport_ipc, force_sharded, selftest_ranks, verify_given, speedup, one_wave;
     /* transport_shm: any host-callback transport (shm or ipc: both need the page's exchange area); transport_ipc: the direct one */
     uint32_t sizes[64];
     uint32_t n_sizes, steps, warmup, galaxies, repeats, verify_steps;
@@ -260,15 +261,25 @@ static uint64_t fnv1a(const void *data, size_t bytes) {
     return h;
 }
 
+/* --one-wave: one receiver per lane, one wave per workgroup -- the launch shape whose summation order does not depend on
+ * how the sources are cut up, so that P shards and one GPU give the same BITS (a test hook, nbody_hip_tuning.h) */
+static World *shaped(const Options *o, World *w) {
+    if (o->one_wave) {
+        nb_hip_tune(GetWorldPipeline(w), "k", 1);
+        nb_hip_tune(GetWorldPipeline(w), "w", 1);
+    }
+    return w;
+}
+
 static World *make_sharded_world(const Options *o, NbRankPage *pg, const Particle *ps, uint32_t n) {
     const int rank = nb_rank_page_rank(pg), P = nb_rank_page_nranks(pg);
-    if (o->transport_ipc) return CreateWorldShardedDirect(ps, n, rank, P, nb_rank_allgather, pg);
-    if (o->transport_shm) return CreateWorldShardedWith(ps, n, rank, P, nb_rank_allgather, pg);
+    if (o->transport_ipc) return shaped(o, CreateWorldShardedDirect(ps, n, rank, P, nb_rank_allgather, pg));
+    if (o->transport_shm) return shaped(o, CreateWorldShardedWith(ps, n, rank, P, nb_rank_allgather, pg));
     unsigned char id[NB_HIP_UNIQUE_ID_BYTES];
     memset(id, 0, sizeof id);
     if (rank == 0) nb_hip_comm_unique_id(id); /* one id per communicator: a fresh one for every World */
     nb_rank_share_id(pg, id);
-    return CreateWorldSharded(ps, n, rank, P, id);
+    return shaped(o, CreateWorldSharded(ps, n, rank, P, id));
 }
 
 static void set_mode(World *w, int mode) {
@@ -282,7 +293,7 @@ static void set_mode(World *w, int mode) {
 static int verify_row(const Options *o, NbRankPage *pg, const Particle *ps, uint32_t n) {
     const int rank = nb_rank_page_rank(pg);
     World *w = make_sharded_world(o, pg, ps, n);
-    World *one = rank == 0 ? CreateWorld(ps, n) : NULL;
+    World *one = rank == 0 ? shaped(o, CreateWorld(ps, n)) : NULL;
     int bad = 0;
     for (int mi = 0; mi < o->n_modes; mi++) {
         set_mode(w, o->modes[mi]);
@@ -346,7 +357,7 @@ static int run_rank(const Options *o, NbRankPage *pg) {
         double single_s = 0.0; /* --speedup: the same call on one GPU, timed by rank 0 while the others wait at the barrier */
         if (o->speedup) {
             if (rank == 0) {
-                World *one = CreateWorld(ps, n);
+                World *one = shaped(o, CreateWorld(ps, n));
                 single_s = time_backend(one, UpdateWorld_GPU, o->dt, o->warmup, o->steps, o->repeats);
                 DestroyWorld(one);
             }
@@ -578,6 +589,8 @@ int main(int argc, char **argv) {
             o.wait_timeout_s = strtod(val, NULL), a++;
         } else if (!strcmp(arg, "--force-sharded")) {
             o.force_sharded = true;
+        } else if (!strcmp(arg, "--one-wave")) {
+            o.one_wave = true;
         } else if (!strcmp(arg, "--speedup")) {
             o.speedup = true;
         } else if (!strcmp(arg, "--selftest-ranks")) {
@@ -588,7 +601,7 @@ int main(int argc, char **argv) {
             fprintf(stderr,
                     "usage: %s [--cpu|--gpu] [--n N]... [--steps K] [--warmup W] [--dt DT] [--galaxies G] [--seed S]"
                     " [--own-rng] [--repeats R] [--floor-rate INT_PER_S]\n"
-                    "       [--gpus P [--transport rccl|ipc|shm] [--modes plain,overlap,graph] [--verify K] [--speedup] [--force-sharded]"
+                    "       [--gpus P [--transport rccl|ipc|shm] [--modes plain,overlap,graph] [--verify K] [--speedup] [--force-sharded] [--one-wave]"
                     " [--wait-timeout S] [--selftest-ranks]]\n",
                     argv[0]);
             return 2;

@@ -255,7 +255,7 @@ extern "C" int nb_hip_probe_clock(double target_ms, double *clock_ghz, double *c
 
     float host_src[24];
     for (int u = 0; u < 8; u++) {
-        host_src[2 * u] = 10.0f * (float)u;
+        host_src[2 * u] = 11.0f * (float)u;
         host_src[2 * u + 1] = -7.0f * (float)u;
         host_src[16 + u] = 1.0e4f + (float)u;
     }

@@ -6,7 +6,7 @@
 // first needs the GPU (SetSimulationData), so CPU-only worlds never initialise HIP.
 #include "pipeline_internal.h"
 
-#define NB_HIP_VERSION 200  // 0.2.0: + CreateSimPipelineShardedDirect, nb_hip_plan_fused_finish, the "fused_finish" knob
+#define NB_HIP_VERSION 300  // 0.3.0: launch-shape / experiment knobs left the ABI (nbody_hip_tuning.h); + nb_hip_probe_clock, nb_hip_clock_sampler_*
 
 namespace nbi {
 
@@ -26,6 +26,7 @@ void ensure_device() {
     // PerformSimUpdate is synchronous by contract (the reference blocks on its fence, sim_gpu.c:353): how fast the host
     // notices completion is part of a short step.  NB_HIP_WAIT=spin|yield|block picks the runtime's wait policy before
     // the context exists; default: the runtime's.
+#ifdef NB_TUNING_SHAPES
     if (const char *wp = getenv("NB_HIP_WAIT")) {
         const unsigned flag = !strcmp(wp, "spin") ? hipDeviceScheduleSpin
                               : !strcmp(wp, "yield") ? hipDeviceScheduleYield
@@ -33,6 +34,7 @@ void ensure_device() {
                                                      : hipDeviceScheduleAuto;
         if (hipSetDeviceFlags(flag) != hipSuccess) (void)hipGetLastError();  // context already live: keep its policy
     }
+#endif
     hipDeviceProp_t prop;
     ASSERT_HIP(hipGetDeviceProperties(&prop, ord), "hipGetDeviceProperties(%d)", ord);
     NB_ASSERT(strncmp(prop.gcnArchName, "gfx950", 6) == 0,

@@ -442,6 +442,9 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
     }
 
     if constexpr (FUSED) {
+        // EVERY workgroup must reach this tail: there is no early return anywhere above, and none may be added -- a
+        // workgroup that left without drawing its ticket would leave its tile unfinished in this launch and the ticket
+        // non-zero for the next (the host re-zeroes the tickets at every upload and chain build, step_chain.hip zero_tickets).
         // The last workgroup of this receiver tile to get here adds the parts, in part order like finish_kernel, and
         // integrates.  Every thread's part stores have been acknowledged (vmcnt(0)) before the workgroup takes its ticket;
         // the last arriver therefore finds all parts written, and reads them with the same scope they were written with.

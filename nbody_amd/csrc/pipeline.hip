@@ -8,6 +8,7 @@
 // The rest of the seam lives next door: device_ctx.hip (device pick), step_chain.hip (what a step call enqueues),
 // rccl_bind.hip + shard_plan.hip (the sharded pipeline's communicator and ownership plan), kernels.hip (gfx950 code).
 #include "pipeline_internal.h"
+#include "nbody_hip_tuning.h"
 
 using namespace nbi;
 
@@ -85,6 +86,7 @@ void release_device(SimPipeline *s) {
     s->parts_cap = 0;
     dev_free(s->tickets);
     s->tickets = nullptr;
+    s->tickets_len = 0;
     ASSERT_HIP(hipEventDestroy(s->ev_begin), "event");
     ASSERT_HIP(hipEventDestroy(s->ev_end), "event");
     ASSERT_HIP(hipEventDestroy(s->ev_local), "event");
@@ -200,32 +202,22 @@ SimPipeline *CreateSimPipeline(WorldData data) {
     SimPipeline *s = new SimPipeline();
     s->data = data;
     s->plan = nb_hip_shard_plan(data.total_len, data.mass_len, 0, 1);
+    // presets from the environment: the knobs of include/nbody_hip.h only; launch-shape and experiment knobs can be preset
+    // in TUNING=1 builds (tools/ sweeps), never in the library that ships
     const char *v = getenv("NB_HIP_VARIANT");
     if (v) s->want_variant = atoi(v) ? nb::VARIANT_SMEM : nb::VARIANT_LDS;
-    const char *k = getenv("NB_HIP_K");
-    if (k) s->want_k = atoi(k);
-    const char *w = getenv("NB_HIP_W");
-    if (w) s->want_w = atoi(w);
-    const char *ps = getenv("NB_HIP_PASSES");
-    if (ps) s->want_passes = atoi(ps);
-    const char *un = getenv("NB_HIP_UNIT");
-    if (un) s->want_unit = atoi(un);
-    const char *sp = getenv("NB_HIP_SPLIT");
-    if (sp) s->want_split = atoi(sp);
-    const char *rb = getenv("NB_HIP_READBACK");
-    if (rb) s->readback = atoi(rb) < 0 || atoi(rb) > 2 ? 2 : atoi(rb);
-    const char *zc = getenv("NB_HIP_ZERO_COPY_UPLOAD");
-    if (zc) s->zero_copy_upload = atoi(zc) ? 1 : 0;
-    const char *tm = getenv("NB_HIP_TIMING");
-    if (tm) s->timing = atoi(tm) ? 1 : 0;
-    const char *ln = getenv("NB_HIP_LANES");
-    if (ln) s->want_lanes = atoi(ln);
-    const char *fc = getenv("NB_HIP_FUSED_CHAIN");
-    if (fc) s->fused_chain = atoi(fc) < 0 || atoi(fc) > 2 ? 2 : atoi(fc);
-    const char *ff = getenv("NB_HIP_FUSED_FINISH");
-    if (ff) s->fused_finish = atoi(ff) < 0 || atoi(ff) > 2 ? 2 : atoi(ff);
     const char *gr = getenv("NB_HIP_GRAPH");
     if (gr) s->use_graph = atoi(gr) < 0 || atoi(gr) > 2 ? 2 : atoi(gr);
+#ifdef NB_TUNING_SHAPES
+    struct { const char *env, *key; } presets[] = {
+        {"NB_HIP_K", "k"}, {"NB_HIP_W", "w"}, {"NB_HIP_SPLIT", "split"}, {"NB_HIP_UNIT", "unit"}, {"NB_HIP_PASSES", "passes"},
+        {"NB_HIP_LANES", "lanes"}, {"NB_HIP_FUSED_CHAIN", "fused_chain"}, {"NB_HIP_FUSED_FINISH", "fused_finish"},
+        {"NB_HIP_READBACK", "readback"}, {"NB_HIP_ZERO_COPY_UPLOAD", "zero_copy_upload"},
+    };
+    for (const auto &p : presets)
+        if (const char *e = getenv(p.env)) nb_hip_tune(s, p.key, atoi(e));
+    if (const char *tm = getenv("NB_HIP_TIMING")) s->timing = atoi(tm) ? 1 : 0;
+#endif
     return s;
 }
 
@@ -387,6 +379,7 @@ void set_simulation_data(SimPipeline *s, const Particle *ps) {
     s->cur = 0;
     s->host_current = false;
     s->updates_since_get = 0;
+    zero_tickets(s);   // a new state starts from clean tile tickets whatever the previous launches did
     // The noted, page-locked array is readable from the device: the split kernel pulls the records over PCIe itself
     // (one launch) instead of a DMA copy into the device staging followed by the kernel (two submissions' latency).
     const bool zero_copy = !s->sharded && ps == s->host_array && s->host_dev != nullptr && s->zero_copy_upload &&
@@ -600,7 +593,33 @@ int nb_hip_configure(SimPipeline *s, const char *key, int value) {
         NB_ASSERT(value == 0 || value == 1, "variant must be 0 (lds) or 1 (smem), got %d", value);
         old = s->want_variant;
         s->want_variant = value;
-    } else if (!strcmp(key, "k")) {
+    } else if (!strcmp(key, "graph")) {
+        NB_ASSERT(value >= 0 && value <= 2, "graph must be 0 (never), 1 (always) or 2 (from the second use), got %d", value);
+        old = s->use_graph;
+        s->use_graph = value;
+    } else if (!strcmp(key, "timing")) {
+        old = s->timing;
+        s->timing = value ? 1 : 0;
+    } else if (!strcmp(key, "sharded_graph")) {
+        old = s->sharded_graph;
+        s->sharded_graph = value ? 1 : 0;
+    } else if (!strcmp(key, "overlap")) {
+        old = s->overlap;
+        if (s->on_device && s->sharded) nb_hip_sync(s);
+        s->overlap = value ? 1 : 0;
+        if (s->on_device && s->overlap && s->sharded)
+            ASSERT_HIP(hipEventRecord(s->ev_gather, s->group ? s->stream : s->comm_stream), "prime gather event");
+    } else {
+        NB_FAIL("unknown knob \"%s\" (include/nbody_hip.h lists the knobs; launch-shape hooks: nbody_hip_tuning.h)", key);
+    }
+    return old;
+}
+
+// Test / tooling hooks (nbody_hip_tuning.h): not part of the C-ABI.
+int nb_hip_tune(SimPipeline *s, const char *key, int value) {
+    NB_ASSERT(s != nullptr && key != nullptr, "NULL argument");
+    int old = 0;
+    if (!strcmp(key, "k")) {
         NB_ASSERT(value == 0 || value == 1 || value == 2 || value == 4, "k must be 0, 1, 2 or 4, got %d", value);
         old = s->want_k;
         s->want_k = value;
@@ -617,10 +636,6 @@ int nb_hip_configure(SimPipeline *s, const char *key, int value) {
         NB_ASSERT(value == 0 || value == 8 || value == 16 || value == 32 || value == 64, "unit must be 0, 8, 16, 32 or 64, got %d", value);
         old = s->want_unit;
         s->want_unit = value;
-    } else if (!strcmp(key, "graph")) {
-        NB_ASSERT(value >= 0 && value <= 2, "graph must be 0 (never), 1 (always) or 2 (from the second use), got %d", value);
-        old = s->use_graph;
-        s->use_graph = value;
     } else if (!strcmp(key, "lanes")) {
         NB_ASSERT(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, "lanes must be 0 (auto), 1, 2, 4 or 8, got %d", value);
         old = s->want_lanes;
@@ -650,20 +665,8 @@ int nb_hip_configure(SimPipeline *s, const char *key, int value) {
     } else if (!strcmp(key, "zero_copy_upload")) {
         old = s->zero_copy_upload;
         s->zero_copy_upload = value ? 1 : 0;
-    } else if (!strcmp(key, "timing")) {
-        old = s->timing;
-        s->timing = value ? 1 : 0;
-    } else if (!strcmp(key, "sharded_graph")) {
-        old = s->sharded_graph;
-        s->sharded_graph = value ? 1 : 0;
-    } else if (!strcmp(key, "overlap")) {
-        old = s->overlap;
-        if (s->on_device && s->sharded) nb_hip_sync(s);
-        s->overlap = value ? 1 : 0;
-        if (s->on_device && s->overlap && s->sharded)
-            ASSERT_HIP(hipEventRecord(s->ev_gather, s->group ? s->stream : s->comm_stream), "prime gather event");
     } else {
-        NB_FAIL("unknown knob \"%s\"", key);
+        NB_FAIL("unknown tuning hook \"%s\"", key);
     }
     return old;
 }

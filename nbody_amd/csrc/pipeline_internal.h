@@ -73,18 +73,36 @@ void dev_free(void *p);
 // from it (src/bench.c:42,53), between GPU calls.  The HIP runtime's first stream / allocation / code-object set-up
 // draws from (or reseeds) that same process-global state -- measured: tools/rand_probe.py, profiles/r04_rand_probe.txt --
 // so the first device set-up of a pipeline and RCCL's bootstrap run with a private state swapped in.
+// initstate / setstate swap ONE process-global pointer, so two guards alive at once on different threads would hand each
+// other's private state back to the caller (and a rand() on a third thread would draw from whichever is current): the
+// guard therefore holds a process-wide mutex for its lifetime -- device set-up of two pipelines on two threads is
+// serialised, which costs nothing (the HIP runtime serialises it anyway) -- and is recursive on one thread (comm_create
+// runs inside SetSimulationData's guard on some paths).  A caller's own rand() racing a guard on another thread is the
+// caller's race: libc's rand() is not thread-safe to begin with (tests/test_abi.py pins the two-guard case).
 class RandGuard {
   public:
-    RandGuard() { old_ = initstate(1u, buf_, sizeof buf_); }
+    RandGuard() {
+        gate().lock();
+        if (depth()++ == 0) old_ = initstate(1u, buf_, sizeof buf_);
+    }
     ~RandGuard() {
-        if (old_) setstate(old_);
+        if (--depth() == 0 && old_) setstate(old_);
+        gate().unlock();
     }
     RandGuard(const RandGuard &) = delete;
     RandGuard &operator=(const RandGuard &) = delete;
 
   private:
+    static std::recursive_mutex &gate() {
+        static std::recursive_mutex m;
+        return m;
+    }
+    static int &depth() {   // guarded by gate(): nesting depth on the owning thread
+        static int d = 0;
+        return d;
+    }
     char buf_[128];
-    char *old_;
+    char *old_ = nullptr;
 };
 
 template <typename T>
@@ -101,8 +119,9 @@ inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 // pipeline (PerformSimUpdate's sync, the collective GetSimulationData) -- runs under a watchdog that prints what was
 // being waited for, the tail of RCCL's own log when NCCL_DEBUG_FILE names one, and _exit(3)s.  No retry and no
 // re-exec: the process has initialised the GPU.  NB_HIP_COMM_TIMEOUT_S (default 180) sets the bound; 0 disables it.
-// One long-lived thread per process does the watching; a Watchdog object only arms it with a deadline and disarms it
-// again (a mutex and a notify: a frame loop of short sharded calls does not pay a thread spawn + join per sync).
+// One long-lived thread per process does the watching; a Watchdog object only adds its deadline to the watcher's list and
+// takes it off again (a mutex and a notify: a frame loop of short sharded calls does not pay a thread spawn + join per
+// sync).  Waits nest per THREAD (an inner wait keeps the outer deadline); waits on different threads are each watched.
 class Watchdog {
   public:
     Watchdog(const char *what, int rank, int nranks);
@@ -111,7 +130,7 @@ class Watchdog {
     Watchdog &operator=(const Watchdog &) = delete;
 
   private:
-    bool armed_ = false;
+    uint64_t seq_ = 0;   // 0: not armed by this object (disabled, or an outer wait of the same thread is being watched)
 };
 
 // ncclCommInitRank + cross-check of the communicator's own rank count + a verified probe all-gather, all bounded
@@ -212,7 +231,8 @@ struct SimPipeline {
     int timing = 0;
     float2 *parts = nullptr;    // split steps only: [split][n_real] partial sums
     uint32_t parts_cap = 0;     // float2 elements allocated in parts
-    uint32_t *tickets = nullptr;  // "fused_finish" experiment: one arrival counter per receiver tile (n_real / 64 + 1), zeroed
+    uint32_t *tickets = nullptr;  // fused finish: one arrival counter per receiver tile, zero between launches (re-zeroed at every upload
+    uint32_t tickets_len = 0;     // and before a chain is built: a launch that ended part-way must not leave a tile unfinished for ever)
     int fused_finish = 2;         // 0: step kernel + finish kernel; 1: the last workgroup of a tile finishes it, whenever
                                   // the shape allows; 2 (default): auto (step_chain.hip fused_finish_rule)
     int cur = 0;             // pos[cur] is the latest state
@@ -258,6 +278,7 @@ nb::LaunchShape resolve_shape(SimPipeline *s);
 bool wants_canonical(const SimPipeline *s);
 StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchShape sh);
 void upload_dt(SimPipeline *s, float dt);
+void zero_tickets(SimPipeline *s);   // fused finish: all tile tickets back to 0, in stream order
 // one sharded step of one rank; `cs` carries the gather (the comm stream with RCCL; the group stream locally)
 void sharded_step(SimPipeline *s, nb::LaunchShape sh, float dt, hipStream_t cs, bool detail = false);
 // in-place all-gather of a device array of nranks slots through the caller's host transport

@@ -77,31 +77,46 @@ namespace nbi {
 
 namespace {
 
-// the process' one watcher thread: sleeps until armed, then until the deadline or the disarm, whichever comes first
+// the process' one watcher thread: holds one entry per thread that is inside a bounded wait and sleeps until the
+// EARLIEST deadline (or a change of the list), so waits on several threads -- several sharded pipelines, local groups
+// driven from threads -- are each watched, not only the first one
 struct Watcher {
+    struct Entry {
+        uint64_t seq;
+        std::thread::id owner;
+        std::chrono::steady_clock::time_point deadline;
+        const char *what;
+        int rank, nranks, seconds;
+    };
     std::mutex m;
     std::condition_variable cv;
     std::thread th;
     bool started = false;
-    uint64_t armed_seq = 0;   // 0 = idle; otherwise the id of the wait being watched
     uint64_t next_seq = 1;
-    std::chrono::steady_clock::time_point deadline;
-    const char *what = "";
-    int rank = 0, nranks = 1, seconds = 0;
+    std::vector<Entry> armed;
 
     void run() {
         std::unique_lock<std::mutex> l(m);
         for (;;) {
-            cv.wait(l, [this] { return armed_seq != 0; });
-            const uint64_t watching = armed_seq;
-            if (cv.wait_until(l, deadline, [&] { return armed_seq != watching; })) continue;  // disarmed (or re-armed) in time
-            give_up();
+            if (armed.empty()) {
+                cv.wait(l, [this] { return !armed.empty(); });
+                continue;
+            }
+            size_t first = 0;
+            for (size_t i = 1; i < armed.size(); i++)
+                if (armed[i].deadline < armed[first].deadline) first = i;
+            const Entry e = armed[first];
+            // woken by any arm / disarm: look again; on time-out the entry is still there (same seq) -> it never completed
+            if (cv.wait_until(l, e.deadline) == std::cv_status::timeout) {
+                for (const Entry &x : armed)
+                    if (x.seq == e.seq) give_up(x);
+            }
         }
     }
 
-    [[noreturn]] void give_up() {
-        fprintf(stderr, "%s [watchdog] rank %d of %d: %s did not complete within %d s; giving up (exit 3)\n", __FILE__, rank, nranks, what,
-                seconds);
+    [[noreturn]] void give_up(const Entry &e) {
+        fprintf(stderr, "%s [watchdog] rank %d of %d: %s did not complete within %d s; giving up (exit 3)\n", __FILE__, e.rank, e.nranks, e.what,
+                e.seconds);
         const char *log = getenv("NCCL_DEBUG_FILE");
         if (log && !strchr(log, '%')) {
             if (FILE *f = fopen(log, "r")) {
@@ -134,29 +149,30 @@ Watchdog::Watchdog(const char *what, int rank, int nranks) {
     Watcher &w = watcher();
     {
         std::lock_guard<std::mutex> l(w.m);
-        if (w.armed_seq != 0) return;  // an outer wait is already being watched: its deadline stands
+        const std::thread::id me = std::this_thread::get_id();
+        for (const Watcher::Entry &e : w.armed)
+            if (e.owner == me) return;  // an outer wait of THIS thread is already being watched: its deadline stands
         if (!w.started) {
             w.started = true;
             w.th = std::thread([&w] { w.run(); });
             w.th.detach();
         }
-        w.what = what;
-        w.rank = rank;
-        w.nranks = nranks;
-        w.seconds = seconds;
-        w.deadline = std::chrono::steady_clock::now() + std::chrono::seconds(seconds);
-        w.armed_seq = w.next_seq++;
-        armed_ = true;
+        seq_ = w.next_seq++;
+        w.armed.push_back({seq_, me, std::chrono::steady_clock::now() + std::chrono::seconds(seconds), what, rank, nranks, seconds});
     }
     w.cv.notify_all();
 }
 
 Watchdog::~Watchdog() {
-    if (!armed_) return;
+    if (seq_ == 0) return;
     Watcher &w = watcher();
     {
         std::lock_guard<std::mutex> l(w.m);
-        w.armed_seq = 0;
+        for (size_t i = 0; i < w.armed.size(); i++)
+            if (w.armed[i].seq == seq_) {
+                w.armed.erase(w.armed.begin() + (long)i);
+                break;
+            }
     }
     w.cv.notify_all();
 }

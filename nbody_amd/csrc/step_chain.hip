@@ -78,9 +78,9 @@ nb::LaunchShape resolve_shape(SimPipeline *s) {
             s->parts = dev_alloc<float2>(need);
             s->parts_cap = (uint32_t)need;
             if (!s->tickets) {
-                const size_t tiles = (size_t)s->n_real / 64 + 2;
-                s->tickets = dev_alloc<uint32_t>(tiles);
-                ASSERT_HIP(hipMemsetAsync(s->tickets, 0, tiles * sizeof(uint32_t), s->stream), "zero the tile tickets");
+                s->tickets_len = (uint32_t)((size_t)s->n_real / 64 + 2);
+                s->tickets = dev_alloc<uint32_t>(s->tickets_len);
+                zero_tickets(s);
                 ASSERT_HIP(hipStreamSynchronize(s->stream), "sync after zeroing the tickets");
             }
             for (auto &g : s->graphs) destroy_graph(g);  // cached nodes point at the old buffer
@@ -207,6 +207,15 @@ void launch_step(SimPipeline *s, nb::LaunchShape sh, const nb::StepParams &p, hi
     }
 }
 
+// The fused finish counts arrivals per receiver tile and its last arriver puts the ticket back to zero -- which only holds
+// while every launch runs to its end.  A launch that ended part-way (a failed graph replay, a device error the caller
+// survived) would leave non-zero tickets, and every later step would silently skip that tile's integration: so the tickets
+// are re-zeroed, in stream order, whenever a new state is uploaded and before a chain is built.
+void zero_tickets(SimPipeline *s) {
+    if (s->tickets && s->tickets_len)
+        ASSERT_HIP(hipMemsetAsync(s->tickets, 0, (size_t)s->tickets_len * sizeof(uint32_t), s->stream), "zero the tile tickets");
+}
+
 // The step size of everything enqueued from here on.  Written in stream order, so steps already queued keep theirs.
 void upload_dt(SimPipeline *s, float dt) {
     if (s->dt_valid && memcmp(&dt, &s->dt_enqueued, sizeof dt) == 0) return;
@@ -260,6 +269,7 @@ StepGraph *find_or_build_graph(SimPipeline *s, uint32_t n, float dt, nb::LaunchS
     }
     g->last_use = ++s->use_clock;
     if (!fresh) return g;
+    if (fused) zero_tickets(s);
     hipGraphNode_t prev = nullptr;
     for (uint32_t i = 0; i < n; i++) {
         const std::vector<nb::StepParams> launches = step_passes(s, whole_step(s, (s->cur + i) & 1, dt), sh);

@@ -37,6 +37,25 @@ def test_hip_library_exports_every_declared_symbol():
     assert set(names) == set(nb.HIP_API), "python binding and header disagree"
 
 
+def test_tuning_hooks_are_exported_but_not_part_of_the_public_header():
+    """ABI 0.3.0: launch-shape and experiment knobs left include/nbody_hip.h.  They live on as test /
+    tooling hooks declared in nbody_amd/csrc/nbody_hip_tuning.h: the library exports them, the public header does not
+    mention them, and nb_hip_configure's documentation lists exactly the five knobs a user of the reference harness needs."""
+    public = open(os.path.join(ROOT, "include", "nbody_hip.h")).read()
+    have = exported(nb.HIP_SO)
+    tuning = open(os.path.join(ROOT, "nbody_amd", "csrc", "nbody_hip_tuning.h")).read()
+    for name in nb.TUNE_API:
+        assert name in have and re.search(r"\b%s\s*\(" % name, tuning), name
+        assert not re.search(r"\b%s\s*\(" % name, public), f"{name} is declared in the public header"
+    doc = public[public.index("Run-time knobs"):public.index("int nb_hip_configure")]
+    assert re.findall(r'^ \*   "(\w+)"', doc, flags=re.M) == list(nb.PUBLIC_KNOBS)
+    assert nb.hip_lib().nb_hip_version() >= 300
+    # the environment presets of the shipped library: the documented ones only (the rest exist in TUNING=1 builds)
+    src = open(os.path.join(ROOT, "nbody_amd", "csrc", "pipeline.hip")).read()
+    shipped = src.split("#ifdef NB_TUNING_SHAPES")[0]
+    assert set(re.findall(r'getenv\("(NB_HIP_\w+)"\)', shipped)) == {"NB_HIP_VARIANT", "NB_HIP_GRAPH"}
+
+
 def test_nbody_library_exports_public_surface():
     names = declared_functions("nbody.h") + declared_functions("galaxy.h")
     assert set(names) == {"CreateWorld", "DestroyWorld", "GetWorldParticles", "UpdateWorld_CPU",
@@ -206,7 +225,9 @@ def test_gpu_call_without_gpu_aborts_loudly():
 # `file:line [func] message` to stderr and abort()s.  Each case runs in a child process.
 ERROR_CASES = [
     ("mass_len > total_len", "s = nb.SimPipeline(10, 11)", "mass_len 11 > total_len 10"),
-    ("unknown knob", "s = nb.SimPipeline(10, 5); s.configure(nonsense=1)", 'unknown knob "nonsense"'),
+    ("unknown knob", "s = nb.SimPipeline(10, 5); nb.hip_lib().nb_hip_configure(s._h, b'nonsense', 1)", 'unknown knob "nonsense"'),
+    ("tuning hook is not a public knob", "s = nb.SimPipeline(10, 5); nb.hip_lib().nb_hip_configure(s._h, b'k', 1)", 'unknown knob "k"'),
+    ("unknown tuning hook", "s = nb.SimPipeline(10, 5); s.configure(nonsense=1)", 'unknown tuning hook "nonsense"'),
     ("bad knob value", "s = nb.SimPipeline(10, 5); s.configure(k=3)", "k must be 0, 1, 2 or 4, got 3"),
     ("bad graph mode", "s = nb.SimPipeline(10, 5); s.configure(graph=7)", "graph must be 0"),
     ("update before set", "s = nb.SimPipeline(10, 5); s.update(1, 0.1)", None),
@@ -281,3 +302,100 @@ def test_nbody_bench_rejects_a_captured_graph_over_the_host_transport():
     nb.nbody_lib()
     r = subprocess.run([BENCH_EXE, "--gpus", "2", "--transport", "shm", "--modes", "plain,graph"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "graph needs --transport rccl" in r.stderr
+
+
+# ---- internal C++ helpers with process-global state, pinned without a GPU -----------------------------------
+
+HELPERS_SRC = r'''
+#include "pipeline_internal.h"
+#include <chrono>
+#include <thread>
+#include <atomic>
+using namespace nbi;
+static void nap(int ms) { std::this_thread::sleep_for(std::chrono::milliseconds(ms)); }
+
+int main(int argc, char **argv) {
+    const std::string mode = argc > 1 ? argv[1] : "";
+    if (mode == "rand") {
+        // the caller's stream: srand(123), then three draws -- with two guards alive on two threads in between
+        srand(123);
+        const int want[3] = {rand(), rand(), rand()};
+        srand(123);
+        std::atomic<int> stage{0};
+        std::thread other([&] {
+            RandGuard g;                 // first guard: swaps a private state in
+            stage = 1;
+            for (int i = 0; i < 50; i++) { (void)rand(); nap(2); }   // "HIP set-up" drawing from the private state
+        });
+        while (stage.load() == 0) nap(1);
+        {
+            RandGuard mine;              // second guard on another thread: must wait for the first, not capture its private state
+            RandGuard nested;            // and the same thread may nest (comm_create inside SetSimulationData)
+            (void)rand();
+        }
+        other.join();
+        const int got[3] = {rand(), rand(), rand()};
+        for (int i = 0; i < 3; i++)
+            if (got[i] != want[i]) { printf("rand stream disturbed: draw %d is %d, expected %d\n", i, got[i], want[i]); return 1; }
+        printf("rand stream intact\n");
+        return 0;
+    }
+    if (mode == "watch") {
+        // thread A sits in a long bounded wait; thread B's shorter wait must be watched too (and fire)
+        setenv("NB_HIP_COMM_TIMEOUT_S", "60", 1);
+        std::atomic<int> stage{0};
+        std::thread a([&] {
+            Watchdog dog("a long wait on thread A", 0, 2);
+            Watchdog inner("nested on thread A: the outer deadline stands", 0, 2);
+            stage = 1;
+            nap(8000);
+        });
+        while (stage.load() == 0) nap(1);
+        setenv("NB_HIP_COMM_TIMEOUT_S", "1", 1);
+        {
+            Watchdog quick("a short wait on thread B that completes", 1, 2);
+            nap(100);
+        }
+        printf("first wait on B returned\n");
+        fflush(stdout);
+        Watchdog dog("the wait on thread B that never completes", 1, 2);
+        nap(6000);
+        printf("NOT REACHED\n");
+        a.join();
+        return 0;
+    }
+    return 2;
+}
+'''
+
+
+@pytest.fixture(scope="module")
+def helpers_exe(tmp_path_factory):
+    d = tmp_path_factory.mktemp("helpers")
+    (d / "t.cpp").write_text(HELPERS_SRC)
+    exe = str(d / "t")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+                    "-I" + os.path.join(ROOT, "nbody_amd", "csrc"), str(d / "t.cpp"), "-o", exe, "-L" + nb.LIB_DIR, "-lnbody_hip",
+                    "-Wl,-rpath," + nb.LIB_DIR, "-lpthread"], check=True, capture_output=True, timeout=300)
+    return exe
+
+
+def test_rand_guards_on_two_threads_leave_the_callers_stream_alone(helpers_exe):
+    """RandGuard (pipeline_internal.h) swaps libc's process-global random state around the first device set-up; two guards
+    alive at once on two threads must not hand each other's private state back to the caller: the guard is serialised by a
+    process-wide (recursive) mutex.  The reference harness draws its universes from rand() between GPU calls
+    (src/bench.c:42,53)."""
+    r = subprocess.run([helpers_exe, "rand"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "rand stream intact" in r.stdout, (r.stdout, r.stderr)
+
+
+def test_watchdog_watches_waits_on_every_thread(helpers_exe):
+    """One watcher thread, one entry per waiting thread: while thread A sits in a wait with a 60 s bound, a wait on thread B
+    with a 1 s bound that completes is disarmed without tripping, and one that never completes ends the process with B's
+    diagnostic and exit code 3 -- the single-slot watcher of round 4 left that second wait unbounded."""
+    import time
+    t0 = time.time()
+    r = subprocess.run([helpers_exe, "watch"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3 and time.time() - t0 < 5.0, (r.returncode, r.stdout, r.stderr)
+    assert "first wait on B returned" in r.stdout and "NOT REACHED" not in r.stdout
+    assert "rank 1 of 2: the wait on thread B that never completes did not complete within 1 s" in r.stderr

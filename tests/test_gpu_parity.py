@@ -1611,12 +1611,12 @@ def test_nbody_bench_c_ranks_on_one_gpu_bitwise(P, n, transport):
     each with its own HIP context on this one GPU, one World stepped through CreateWorldShardedWith over the shared page
     (shm: data staged through the host) or CreateWorldShardedDirect (ipc: every rank maps its peers' source arrays with
     hipIpcOpenMemHandle and pushes its slice into them device to device; the page carries handles and one barrier per
-    step) -- no Python, no torch, /opt/rocm's HIP runtime.  With one wave per workgroup (NB_HIP_W=1, NB_HIP_K=1) the
+    step) -- no Python, no torch, /opt/rocm's HIP runtime.  With one wave per workgroup (--one-wave) the
     summation order does not depend on the launch geometry: the in-stream (plain) step must equal the single-GPU World
     bit for bit."""
     import re
     r = _bench_ranks(["--gpus", str(P), "--transport", transport, "--n", str(n), "--steps", "6", "--warmup", "2", "--dt", "0.01",
-                      "--modes", "plain", "--verify", "4"], env={"NB_HIP_W": "1", "NB_HIP_K": "1"})
+                      "--modes", "plain", "--verify", "4", "--one-wave"])
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     v = re.findall(r"verify N=(\d+) mode=(\w+) steps=4: ranks agree (\w+); vs single GPU: rel_l2_pos ([0-9.e+-]+) max_abs_pos ([0-9.e+-]+) bitwise (\w+)", r.stderr)
     assert v == [(str(n), "plain", "yes", v[0][3], v[0][4], "yes")] and float(v[0][3]) == 0.0, r.stderr
