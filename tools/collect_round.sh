@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): everything profiles/<tag>_* is made from, except the rocprofv3 passes
-# (tools/profile.sh, tools/profile_routes.sh, tools/profile_mid_n.sh).  usage: tools/collect_round.sh r04 [full]
+# (tools/profile.sh, tools/profile_routes.sh, tools/profile_mid_n.sh).  usage: tools/collect_round.sh r05 [full]
 # "full" adds the frame-loop / graph-policy probes of round 2 (frozen since: the GUI they serve is out of scope).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 FULL=${2:-}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
@@ -29,6 +29,11 @@ for P in 2 3; do
   python -m torch.distributed.run --nnodes=1 --nproc-per-node $P --master-addr 127.0.0.1 --master-port 2954$P bench.py --gpus $P \
       --transport host --steps 10 --warmup 2 > $O/${TAG}_rehearsal_${P}ranks_host.json 2> $O/${TAG}_rehearsal_${P}ranks_host.err; echo "host-transport P=$P rc=$?"
 done
+# round 5: bench.py started BARE (no launcher): a GPU-free supervisor starts the rank processes itself; with both ranks on this
+# one GPU RCCL refuses the duplicate device, both ranks abort, and --transport auto answers with a fresh set of processes over
+# the direct exchange (the line carries transport_fallback); then three ranks over the direct exchange asked for outright
+python bench.py --gpus 2 --steps 10 --warmup 2 --extra-particles 262144 > $O/${TAG}_bare_2ranks_auto.json 2> $O/${TAG}_bare_2ranks_auto.err; echo "bare --gpus 2 (auto: rccl refused -> direct) rc=$?"
+python bench.py --gpus 3 --transport direct --steps 10 --warmup 2 --extra-particles 262144 > $O/${TAG}_bare_3ranks_direct.json 2> $O/${TAG}_bare_3ranks_direct.err; echo "bare --gpus 3 --transport direct rc=$?"
 # round 4: the C harness' own multi-process mode (ranks forked before any HIP call, shared page, no Python / torch)
 {
   echo "== nbody-bench --gpus 1 --force-sharded --n 20000 --n 1048576 --steps 10 --warmup 2 --dt 0.01: the RCCL path with one rank (ncclCommInitRank, in-place ncclAllGather per step, overlapped step, chain captured as a hipGraph) on /opt/rocm's HIP runtime + librccl =="
