@@ -93,6 +93,9 @@ struct LaunchShape {
     // w * lanes source slices per receiver inside ONE workgroup -- the parallelism a source split buys, without its
     // second kernel.  Latency-bound launches only (k = 1, split = 1, sources staged once in LDS).
     int lanes;
+    // experiment ("persist" hook): > 1 = the launch has 1/persist as many workgroups as (tile, part) work items and every
+    // workgroup walks `persist` of them (scalar-cache route, classic kernel only); 0 / 1 = one workgroup per item
+    int persist;
 };
 
 constexpr uint32_t LANE_SPLIT_MAX_SRC = 1u << 18;   // sources a lane-split launch walks (one launch = one source pass)

@@ -168,6 +168,31 @@ __device__ __forceinline__ void interact8(Receivers<K> &R, const VP &P, const VG
 NB_INTERACT8_OVERRIDE
 #endif
 
+// Source arrays as the scalar-cache route reads them.  A wave-uniform load becomes a scalar load (s_load_dwordx8/x16) only
+// while the compiler can prove that nothing in the kernel has written the memory before it: true by construction in the
+// classic launch (all stores sit in the epilogue), not in a persistent one, where the epilogue of work item i precedes the
+// loads of item i + 1.  The sources ARE read-only for the whole launch (a step reads src_pos[in] and writes pos[in ^ 1] /
+// src_pos[in ^ 1]), which is what the constant address space says: persistent launches read them through it.
+typedef const float __attribute__((address_space(4))) *ConstF;
+template <typename V>
+__device__ __forceinline__ V src_load(const float *ptr) {
+    return *reinterpret_cast<const V *>(ptr);
+}
+template <typename V>
+__device__ __forceinline__ V src_load(ConstF ptr) {
+    return *(const V __attribute__((address_space(4))) *)ptr;
+}
+template <bool READ_ONLY_AS>
+struct SrcPtr {
+    typedef const float *type;
+    static __device__ __forceinline__ type of(const void *ptr) { return static_cast<const float *>(ptr); }
+};
+template <>
+struct SrcPtr<true> {
+    typedef ConstF type;
+    static __device__ __forceinline__ type of(const void *ptr) { return (ConstF)(uintptr_t)ptr; }
+};
+
 // Slot of logical receiver i (see StepParams::recv_split).
 __device__ __forceinline__ uint32_t receiver_slot(const StepParams &p, uint32_t i) {
     return i + (i >= p.recv_split ? p.recv_gap : 0u);
@@ -253,13 +278,25 @@ __global__ __launch_bounds__(256) void finish_kernel(const StepParams p) {
 // per SIMD) would mean ONE resident workgroup per CU instead of two.  The asm body needs 36 (SMEM, K <= 2) / 62 (LDS);
 // the second launch-bound argument (waves per SIMD) makes the limit explicit.  K = 4 then keeps its Kahan state in
 // scratch, touched only at block closes outside the inner loop, and runs as fast as K = 2.
-template <int K, int W, int VARIANT, bool FUSED = false>
+//
+// PERSIST (experiment, tuning hook "persist"): the launch has FEWER workgroups than (receiver tile, source part) work items
+// and every workgroup walks items blockIdx.x, blockIdx.x + gridDim.x, ... -- fewer, longer-lived waves, so that dispatch
+// ramp and end-of-kernel write-back are paid by fewer workgroups.  Same bits as the classic launch: an
+// item is computed by exactly the code a classic workgroup (tile, part) runs.
+template <int K, int W, int VARIANT, bool FUSED = false, bool PERSIST = false>
 __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (WAVE - 1);
     // wave id as an SGPR value so that everything derived from it stays scalar
     const uint32_t wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t recv_base = blockIdx.x * (WAVE * K);
+    // the work item of this workgroup: receiver tile and source part (classic launch: the grid coordinates)
+    uint32_t tile_x = blockIdx.x, part_y = blockIdx.y;
+    [[maybe_unused]] uint32_t item = blockIdx.x;
+    [[maybe_unused]] const uint32_t n_tiles = (p.n_recv + WAVE * K - 1) / (WAVE * K);
+    if constexpr (PERSIST) {
+        tile_x = item % n_tiles;
+        part_y = item / n_tiles;
+    }
 
     // per wave, double-buffered: 64 interleaved (x, y) pairs, then 64 G*m
     __shared__ __attribute__((aligned(16))) float tile[VARIANT == VARIANT_LDS ? W : 1][2][3 * CHUNK];
@@ -270,233 +307,248 @@ __global__ __launch_bounds__(WAVE *W, 8) void step_kernel(const StepParams p) {
     // profiles/r02_ab_early_fetch.txt.)
     const float dt = *p.dt;
 
-    Receivers<K> R;
+#pragma clang loop unroll(disable)
+    for (;;) {
+        const uint32_t recv_base = tile_x * (WAVE * K);
+        Receivers<K> R;
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        uint32_t i = recv_base + k * WAVE + lane;
-        i = i < p.n_recv ? i : p.n_recv - 1;  // tail lanes redo the last receiver; their stores are masked
-        i = receiver_slot(p, i);
-        const float2 q = p.pos_in[i];
-        R.p[k] = f2v{q.x, q.y};
-        R.r[k] = p.radius[i];
-    }
-    R.clear();
-
-    // this wave's slice of the concatenated source ranges, in whole chunks
-    const uint32_t n0 = p.src_end[0] - p.src_begin[0];
-    const uint32_t n1 = p.src_end[1] - p.src_begin[1];
-    const uint32_t total = n0 + n1;
-    // this workgroup's part of the sources (all of them unless the step is split), then this wave's slice of it, both
-    // in whole granules of p.unit sources (64 = one tile; finer for latency-bound launches, see StepParams::unit)
-    const uint32_t unit = p.unit;
-    const uint32_t nunits = (total + unit - 1) / unit;
-    const uint32_t per_part = (nunits + p.split - 1) / p.split;
-    const uint32_t part_lo = min(blockIdx.y * per_part, nunits);
-    const uint32_t part_hi = min(part_lo + per_part, nunits);
-    const uint32_t per_wave = (part_hi - part_lo + W - 1) / W;
-    const uint32_t u_lo = min(part_lo + wid * per_wave, part_hi);
-    const uint32_t u_hi = min(u_lo + per_wave, part_hi);
-    const uint32_t v_lo = u_lo * unit;                // first source of the slice: a multiple of 8
-    const uint32_t v_hi = min(u_hi * unit, total);    // one past its last source
-
-    if constexpr (VARIANT == VARIANT_LDS) {
-        float(*T)[3 * CHUNK] = tile[wid];
-        float2 sp = make_float2(0.f, 0.f);
-        float sg = 0.f;
-        auto fetch = [&](uint32_t c) {
-            const uint32_t v = c * CHUNK + lane;
-            const bool live = v < total;
-            const uint32_t j = source_index(p, live ? v : total - 1, n0);
-            sp = p.src_pos[j];                 // 512 B per wave, coalesced
-            sg = live ? p.src_gm[j] : 0.0f;    // pad sources: a real position, zero mass
-        };
-        // whole 64-source tiles only: this route always runs with the 64-source granule (choose_shape), so the slice
-        // is [c_lo, c_hi) tiles and the last one may be ragged (pads: a real position, zero mass)
-        const uint32_t c_lo = v_lo / CHUNK, c_hi = (v_hi + CHUNK - 1) / CHUNK;
-        if (c_lo < c_hi) fetch(c_lo);
-        int buf = 0;
-        for (uint32_t c = c_lo; c < c_hi; c++) {
-            *reinterpret_cast<float2 *>(&T[buf][2 * lane]) = sp;  // ds_write_b64
-            T[buf][2 * CHUNK + lane] = sg;
-            if (c + 1 < c_hi) fetch(c + 1);  // next tile's HBM/L2 latency hides under this tile's math
-            // LDS executes one wave's accesses in order; this only stops the compiler from reordering
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int jj = 0; jj < CHUNK; jj += 4) {
-                // broadcast ds_read_b128: every lane reads the same 16 bytes.  Four sources per read group (two reads
-                // of positions, one of G*m): 12 staging VGPRs instead of 24, which is what leaves room for the
-                // paired-rsq body with two receivers per lane
-                const v8f P = *reinterpret_cast<const v8f *>(&T[buf][2 * jj]);
-                const v4f G = *reinterpret_cast<const v4f *>(&T[buf][2 * CHUNK + jj]);
-#pragma unroll
-                for (int u = 0; u < 4; u++) interact<K, false>(R, f2v{P[2 * u], P[2 * u + 1]}, G[u]);
-            }
-            if (((c - c_lo) & (CLOSE_EVERY - 1)) == CLOSE_EVERY - 1) R.close_chunk();
-            buf ^= 1;
+        for (int k = 0; k < K; k++) {
+            uint32_t i = recv_base + k * WAVE + lane;
+            i = i < p.n_recv ? i : p.n_recv - 1;  // tail lanes redo the last receiver; their stores are masked
+            i = receiver_slot(p, i);
+            const float2 q = p.pos_in[i];
+            R.p[k] = f2v{q.x, q.y};
+            R.r[k] = p.radius[i];
         }
-        if ((c_hi - c_lo) & (CLOSE_EVERY - 1)) R.close_chunk();  // a short last block
-    } else {
-        // scalar-cache route: indices are wave-uniform, the loads become s_load_dwordx8/x16
-#pragma unroll
-        for (int range = 0; range < 2; range++) {
-            // intersection of [v_lo, v_hi) with this range, as indices of the source arrays
-            const uint32_t r_lo = range == 0 ? 0u : n0;
-            const uint32_t r_hi = range == 0 ? n0 : total;
-            const uint32_t a = max(v_lo, r_lo), b = min(v_hi, r_hi);
-            if (a >= b) continue;
-            uint32_t j = p.src_begin[range] + (a - r_lo);
-            const uint32_t j_end = p.src_begin[range] + (b - r_lo);
-            // 8 sources per scalar fetch: s_load_dwordx16 (x,y pairs) + s_load_dwordx8 (G*m).  Slices start on
-            // multiples of 64 sources from 64-aligned range starts, so j is a multiple of 8 here.
-            const float *__restrict__ sp = reinterpret_cast<const float *>(p.src_pos);
-            const float *__restrict__ sg = p.src_gm;
-            // every 8 * CLOSE_EVERY groups (256 sources) the block sums are closed, exactly where the LDS variant
-            // closes them, so both variants add in the same order; a short last block may end in single sources
-            const uint32_t groups = (j_end - j) / 8;
-            const uint32_t g0 = (a - v_lo) / 8;  // groups of this slice that lie in the previous range
-            if (groups > 0) {
-                // Two register sets, A and B, each fetched while the other one is being consumed (the scalar
-                // cache's latency hides under 8 * K interactions) and each dead before its refill is issued, so
-                // no set is ever copied.  g0 is even (range starts are 64-aligned) and a block ends on an odd
-                // group index, so only the second group of a pair can close one.  The refill address is clamped to
-                // the last group instead of branching around the load.
-                const uint32_t j_last = j + (groups - 1) * 8;
-                v16f PA = *reinterpret_cast<const v16f *>(sp + 2 * (size_t)j);
-                v8f GA = *reinterpret_cast<const v8f *>(sg + j);
-                uint32_t g = 0;
-                while (g + 2 <= groups) {
-                    // pairs up to the end of the current 32-group block, as one branch-free inner loop
-                    const uint32_t to_close = (8u * CLOSE_EVERY - ((g0 + g) & (8u * CLOSE_EVERY - 1))) / 2;
-                    const uint32_t pairs = min(to_close, (groups - g) / 2);
-                    for (uint32_t i = 0; i < pairs; i++) {
-                        // Scalar loads return out of order, so the only wait there is is "all of them"
-                        // (lgkmcnt(0)).  The empty asm makes the next fetch's address depend on the set about to
-                        // be consumed: the wait lands BEFORE that fetch is issued, where nothing is in flight but
-                        // loads that had a whole group's math to land.  (Not volatile: a volatile asm counts as a
-                        // memory clobber and would turn the scalar loads into vector loads.)  The scheduling
-                        // barriers keep each fetch ahead of the math that hides it.
-                        asm("" : "+s"(j) : "s"(PA), "s"(GA));
-                        const v16f PB = *reinterpret_cast<const v16f *>(sp + 2 * (size_t)(j + 8));
-                        const v8f GB = *reinterpret_cast<const v8f *>(sg + j + 8);
-                        __builtin_amdgcn_sched_barrier(0);
-                        interact8<K, true>(R, PA, GA);
-                        __builtin_amdgcn_sched_barrier(0);
-                        j = min(j + 16, j_last);
-                        asm("" : "+s"(j) : "s"(PB), "s"(GB));
-                        PA = *reinterpret_cast<const v16f *>(sp + 2 * (size_t)j);
-                        GA = *reinterpret_cast<const v8f *>(sg + j);
-                        __builtin_amdgcn_sched_barrier(0);
-                        interact8<K, true>(R, PB, GB);
-                    }
-                    g += 2 * pairs;
-                    if (pairs == to_close) R.close_chunk();
-                }
-                if (g < groups) interact8<K, true>(R, PA, GA);  // odd count: the last refill fetched it
-                j = j_last + 8;
-            }
-            for (; j < j_end; j++) interact<K, true>(R, f2v{sp[2 * (size_t)j], sp[2 * (size_t)j + 1]}, sg[j]);
-        }
-        // a short last block: anything after the last multiple of 256 sources of this slice (same blocks as the
-        // LDS variant, whose last tile may be padded)
-        if ((v_hi - v_lo) & (CHUNK * CLOSE_EVERY - 1)) R.close_chunk();
-    }
+        R.clear();
 
-    // ---- combine the W slices in wave order, integrate, store -------------------------------------------
-    auto finish = [&](uint32_t logical, float sx, float sy) {
-        if (p.split > 1) {
-            if (logical < p.n_recv) {
-                float2 *slot = &p.parts[(size_t)blockIdx.y * p.n_recv + logical];
-                if constexpr (FUSED) {
-                    // agent-scope relaxed store (one 8-byte access): written through to the point every XCD's loads of the
-                    // same scope read
-                    const uint64_t bits = (uint64_t)__float_as_uint(sx) | ((uint64_t)__float_as_uint(sy) << 32);
-                    __hip_atomic_store(reinterpret_cast<uint64_t *>(slot), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    *slot = make_float2(sx, sy);
+        // this wave's slice of the concatenated source ranges, in whole chunks
+        const uint32_t n0 = p.src_end[0] - p.src_begin[0];
+        const uint32_t n1 = p.src_end[1] - p.src_begin[1];
+        const uint32_t total = n0 + n1;
+        // this workgroup's part of the sources (all of them unless the step is split), then this wave's slice of it, both
+        // in whole granules of p.unit sources (64 = one tile; finer for latency-bound launches, see StepParams::unit)
+        const uint32_t unit = p.unit;
+        const uint32_t nunits = (total + unit - 1) / unit;
+        const uint32_t per_part = (nunits + p.split - 1) / p.split;
+        const uint32_t part_lo = min(part_y * per_part, nunits);
+        const uint32_t part_hi = min(part_lo + per_part, nunits);
+        const uint32_t per_wave = (part_hi - part_lo + W - 1) / W;
+        const uint32_t u_lo = min(part_lo + wid * per_wave, part_hi);
+        const uint32_t u_hi = min(u_lo + per_wave, part_hi);
+        const uint32_t v_lo = u_lo * unit;                // first source of the slice: a multiple of 8
+        const uint32_t v_hi = min(u_hi * unit, total);    // one past its last source
+
+        if constexpr (VARIANT == VARIANT_LDS) {
+            float(*T)[3 * CHUNK] = tile[wid];
+            float2 sp = make_float2(0.f, 0.f);
+            float sg = 0.f;
+            auto fetch = [&](uint32_t c) {
+                const uint32_t v = c * CHUNK + lane;
+                const bool live = v < total;
+                const uint32_t j = source_index(p, live ? v : total - 1, n0);
+                sp = p.src_pos[j];                 // 512 B per wave, coalesced
+                sg = live ? p.src_gm[j] : 0.0f;    // pad sources: a real position, zero mass
+            };
+            // whole 64-source tiles only: this route always runs with the 64-source granule (choose_shape), so the slice
+            // is [c_lo, c_hi) tiles and the last one may be ragged (pads: a real position, zero mass)
+            const uint32_t c_lo = v_lo / CHUNK, c_hi = (v_hi + CHUNK - 1) / CHUNK;
+            if (c_lo < c_hi) fetch(c_lo);
+            int buf = 0;
+            for (uint32_t c = c_lo; c < c_hi; c++) {
+                *reinterpret_cast<float2 *>(&T[buf][2 * lane]) = sp;  // ds_write_b64
+                T[buf][2 * CHUNK + lane] = sg;
+                if (c + 1 < c_hi) fetch(c + 1);  // next tile's HBM/L2 latency hides under this tile's math
+                // LDS executes one wave's accesses in order; this only stops the compiler from reordering
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int jj = 0; jj < CHUNK; jj += 4) {
+                    // broadcast ds_read_b128: every lane reads the same 16 bytes.  Four sources per read group (two reads
+                    // of positions, one of G*m): 12 staging VGPRs instead of 24, which is what leaves room for the
+                    // paired-rsq body with two receivers per lane
+                    const v8f P = *reinterpret_cast<const v8f *>(&T[buf][2 * jj]);
+                    const v4f G = *reinterpret_cast<const v4f *>(&T[buf][2 * CHUNK + jj]);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) interact<K, false>(R, f2v{P[2 * u], P[2 * u + 1]}, G[u]);
                 }
+                if (((c - c_lo) & (CLOSE_EVERY - 1)) == CLOSE_EVERY - 1) R.close_chunk();
+                buf ^= 1;
             }
+            if ((c_hi - c_lo) & (CLOSE_EVERY - 1)) R.close_chunk();  // a short last block
         } else {
-            finish_receiver(p, logical, sx, sy, dt);
-        }
-    };
-
-    if constexpr (W == 1) {
+            // scalar-cache route: indices are wave-uniform, the loads become s_load_dwordx8/x16
 #pragma unroll
-        for (int k = 0; k < K; k++) finish(recv_base + k * WAVE + lane, R.s[k].x, R.s[k].y);
-    } else {
-#pragma unroll
-        for (int k = 0; k < K; k++) partial[wid][k * WAVE + lane] = make_float2(R.s[k].x, R.s[k].y);
-        __syncthreads();
-#pragma unroll
-        for (uint32_t slot = tid; slot < WAVE * K; slot += WAVE * W) {
-            float sx = 0.0f, sy = 0.0f;
-#pragma unroll
-            for (int s = 0; s < W; s++) {
-                const float2 t = partial[s][slot];
-                sx = __fadd_rn(sx, t.x);
-                sy = __fadd_rn(sy, t.y);
-            }
-            finish(recv_base + slot, sx, sy);
-        }
-    }
-
-    if constexpr (FUSED) {
-        // EVERY workgroup must reach this tail: there is no early return anywhere above, and none may be added -- a
-        // workgroup that left without drawing its ticket would leave its tile unfinished in this launch and the ticket
-        // non-zero for the next (the host re-zeroes the tickets at every upload and chain build, step_chain.hip zero_tickets).
-        // The last workgroup of this receiver tile to get here adds the parts, in part order like finish_kernel, and
-        // integrates.  Every thread's part stores have been acknowledged (vmcnt(0)) before the workgroup takes its ticket;
-        // the last arriver therefore finds all parts written, and reads them with the same scope they were written with.
-        if (p.split > 1) {
-            __shared__ uint32_t is_last;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                const uint32_t t = __hip_atomic_fetch_add(&p.tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                is_last = t == p.split - 1 ? 1u : 0u;
-                if (is_last) __hip_atomic_store(&p.tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
-            }
-            __syncthreads();
-            if (is_last) {
-                for (uint32_t slot = tid; slot < WAVE * K; slot += WAVE * W) {
-                    const uint32_t logical = recv_base + slot;
-                    if (logical >= p.n_recv) continue;
-                    // like finish_kernel: every part load issued before the first use (unused slots re-read the last part
-                    // and are dropped by a select), or the loads would queue up behind each other's round trips
-                    uint64_t bits[MAX_SPLIT];
-#pragma unroll
-                    for (uint32_t s = 0; s < (uint32_t)MAX_SPLIT; s++)
-                        bits[s] = __hip_atomic_load(reinterpret_cast<const uint64_t *>(&p.parts[(size_t)(s < p.split ? s : p.split - 1) * p.n_recv + logical]),
-                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    // the integrator's state rides the same round trip (finish_receiver would fetch it behind the sums)
-                    const uint32_t i = receiver_slot(p, logical);
-                    const float2 a0 = p.acc[i], v0 = p.vel[i], q0 = p.pos_in[i];
-                    float sx = 0.0f, sy = 0.0f;
-#pragma unroll
-                    for (uint32_t s = 0; s < (uint32_t)MAX_SPLIT; s++) {
-                        const float nx = __fadd_rn(sx, __uint_as_float((uint32_t)bits[s])), ny = __fadd_rn(sy, __uint_as_float((uint32_t)(bits[s] >> 32)));
-                        sx = s < p.split ? nx : sx;
-                        sy = s < p.split ? ny : sy;
+            for (int range = 0; range < 2; range++) {
+                // intersection of [v_lo, v_hi) with this range, as indices of the source arrays
+                const uint32_t r_lo = range == 0 ? 0u : n0;
+                const uint32_t r_hi = range == 0 ? n0 : total;
+                const uint32_t a = max(v_lo, r_lo), b = min(v_hi, r_hi);
+                if (a >= b) continue;
+                uint32_t j = p.src_begin[range] + (a - r_lo);
+                const uint32_t j_end = p.src_begin[range] + (b - r_lo);
+                // 8 sources per scalar fetch: s_load_dwordx16 (x,y pairs) + s_load_dwordx8 (G*m).  Slices start on
+                // multiples of 64 sources from 64-aligned range starts, so j is a multiple of 8 here.
+                const typename SrcPtr<PERSIST>::type sp = SrcPtr<PERSIST>::of(p.src_pos), sg = SrcPtr<PERSIST>::of(p.src_gm);
+                // every 8 * CLOSE_EVERY groups (256 sources) the block sums are closed, exactly where the LDS variant
+                // closes them, so both variants add in the same order; a short last block may end in single sources
+                const uint32_t groups = (j_end - j) / 8;
+                const uint32_t g0 = (a - v_lo) / 8;  // groups of this slice that lie in the previous range
+                if (groups > 0) {
+                    // Two register sets, A and B, each fetched while the other one is being consumed (the scalar
+                    // cache's latency hides under 8 * K interactions) and each dead before its refill is issued, so
+                    // no set is ever copied.  g0 is even (range starts are 64-aligned) and a block ends on an odd
+                    // group index, so only the second group of a pair can close one.  The refill address is clamped to
+                    // the last group instead of branching around the load.
+                    const uint32_t j_last = j + (groups - 1) * 8;
+                    v16f PA = src_load<v16f>(sp + 2 * (size_t)j);
+                    v8f GA = src_load<v8f>(sg + j);
+                    uint32_t g = 0;
+                    while (g + 2 <= groups) {
+                        // pairs up to the end of the current 32-group block, as one branch-free inner loop
+                        const uint32_t to_close = (8u * CLOSE_EVERY - ((g0 + g) & (8u * CLOSE_EVERY - 1))) / 2;
+                        const uint32_t pairs = min(to_close, (groups - g) / 2);
+                        for (uint32_t i = 0; i < pairs; i++) {
+                            // Scalar loads return out of order, so the only wait there is is "all of them"
+                            // (lgkmcnt(0)).  The empty asm makes the next fetch's address depend on the set about to
+                            // be consumed: the wait lands BEFORE that fetch is issued, where nothing is in flight but
+                            // loads that had a whole group's math to land.  (Not volatile: a volatile asm counts as a
+                            // memory clobber and would turn the scalar loads into vector loads.)  The scheduling
+                            // barriers keep each fetch ahead of the math that hides it.
+                            asm("" : "+s"(j) : "s"(PA), "s"(GA));
+                            const v16f PB = src_load<v16f>(sp + 2 * (size_t)(j + 8));
+                            const v8f GB = src_load<v8f>(sg + j + 8);
+                            __builtin_amdgcn_sched_barrier(0);
+                            interact8<K, true>(R, PA, GA);
+                            __builtin_amdgcn_sched_barrier(0);
+                            j = min(j + 16, j_last);
+                            asm("" : "+s"(j) : "s"(PB), "s"(GB));
+                            PA = src_load<v16f>(sp + 2 * (size_t)j);
+                            GA = src_load<v8f>(sg + j);
+                            __builtin_amdgcn_sched_barrier(0);
+                            interact8<K, true>(R, PB, GB);
+                        }
+                        g += 2 * pairs;
+                        if (pairs == to_close) R.close_chunk();
                     }
-                    // same arithmetic, same roundings as finish_receiver / finish_kernel
-                    float2 a = make_float2(sx, sy);
-                    if (p.flags & STEP_ACC_IN) {
-                        a.x = __fadd_rn(a0.x, a.x);
-                        a.y = __fadd_rn(a0.y, a.y);
+                    if (g < groups) interact8<K, true>(R, PA, GA);  // odd count: the last refill fetched it
+                    j = j_last + 8;
+                }
+                for (; j < j_end; j++) interact<K, true>(R, f2v{sp[2 * (size_t)j], sp[2 * (size_t)j + 1]}, sg[j]);
+            }
+            // a short last block: anything after the last multiple of 256 sources of this slice (same blocks as the
+            // LDS variant, whose last tile may be padded)
+            if ((v_hi - v_lo) & (CHUNK * CLOSE_EVERY - 1)) R.close_chunk();
+        }
+
+        // ---- combine the W slices in wave order, integrate, store -------------------------------------------
+        auto finish = [&](uint32_t logical, float sx, float sy) {
+            if (p.split > 1) {
+                if (logical < p.n_recv) {
+                    float2 *slot = &p.parts[(size_t)part_y * p.n_recv + logical];
+                    if constexpr (FUSED) {
+                        // agent-scope relaxed store (one 8-byte access): written through to the point every XCD's loads of the
+                        // same scope read
+                        const uint64_t bits = (uint64_t)__float_as_uint(sx) | ((uint64_t)__float_as_uint(sy) << 32);
+                        __hip_atomic_store(reinterpret_cast<uint64_t *>(slot), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        *slot = make_float2(sx, sy);
                     }
-                    p.acc[i] = a;
-                    if (p.flags & STEP_NO_FINALIZE) continue;
-                    float2 v = v0, q = q0;
-                    v.x = __fadd_rn(v.x, __fmul_rn(a.x, dt));
-                    v.y = __fadd_rn(v.y, __fmul_rn(a.y, dt));
-                    q.x = __fadd_rn(q.x, __fmul_rn(v.x, dt));
-                    q.y = __fadd_rn(q.y, __fmul_rn(v.y, dt));
-                    p.vel[i] = v;
-                    p.pos_out[i] = q;
-                    if (i < p.n_mirror) p.mirror[i] = q;
+                }
+            } else {
+                finish_receiver(p, logical, sx, sy, dt);
+            }
+        };
+
+        if constexpr (W == 1) {
+#pragma unroll
+            for (int k = 0; k < K; k++) finish(recv_base + k * WAVE + lane, R.s[k].x, R.s[k].y);
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; k++) partial[wid][k * WAVE + lane] = make_float2(R.s[k].x, R.s[k].y);
+            __syncthreads();
+#pragma unroll
+            for (uint32_t slot = tid; slot < WAVE * K; slot += WAVE * W) {
+                float sx = 0.0f, sy = 0.0f;
+#pragma unroll
+                for (int s = 0; s < W; s++) {
+                    const float2 t = partial[s][slot];
+                    sx = __fadd_rn(sx, t.x);
+                    sy = __fadd_rn(sy, t.y);
+                }
+                finish(recv_base + slot, sx, sy);
+            }
+        }
+
+        if constexpr (FUSED) {
+            // EVERY workgroup must reach this tail: there is no early return anywhere above, and none may be added -- a
+            // workgroup that left without drawing its ticket would leave its tile unfinished in this launch and the ticket
+            // non-zero for the next (the host re-zeroes the tickets at every upload and chain build, step_chain.hip zero_tickets).
+            // The last workgroup of this receiver tile to get here adds the parts, in part order like finish_kernel, and
+            // integrates.  Every thread's part stores have been acknowledged (vmcnt(0)) before the workgroup takes its ticket;
+            // the last arriver therefore finds all parts written, and reads them with the same scope they were written with.
+            if (p.split > 1) {
+                __shared__ uint32_t is_last;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    const uint32_t t = __hip_atomic_fetch_add(&p.tickets[tile_x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    is_last = t == p.split - 1 ? 1u : 0u;
+                    if (is_last) __hip_atomic_store(&p.tickets[tile_x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+                }
+                __syncthreads();
+                if (is_last) {
+                    for (uint32_t slot = tid; slot < WAVE * K; slot += WAVE * W) {
+                        const uint32_t logical = recv_base + slot;
+                        if (logical >= p.n_recv) continue;
+                        // like finish_kernel: every part load issued before the first use (unused slots re-read the last part
+                        // and are dropped by a select), or the loads would queue up behind each other's round trips
+                        uint64_t bits[MAX_SPLIT];
+#pragma unroll
+                        for (uint32_t s = 0; s < (uint32_t)MAX_SPLIT; s++)
+                            bits[s] = __hip_atomic_load(reinterpret_cast<const uint64_t *>(&p.parts[(size_t)(s < p.split ? s : p.split - 1) * p.n_recv + logical]),
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // the integrator's state rides the same round trip (finish_receiver would fetch it behind the sums)
+                        const uint32_t i = receiver_slot(p, logical);
+                        const float2 a0 = p.acc[i], v0 = p.vel[i], q0 = p.pos_in[i];
+                        float sx = 0.0f, sy = 0.0f;
+#pragma unroll
+                        for (uint32_t s = 0; s < (uint32_t)MAX_SPLIT; s++) {
+                            const float nx = __fadd_rn(sx, __uint_as_float((uint32_t)bits[s])), ny = __fadd_rn(sy, __uint_as_float((uint32_t)(bits[s] >> 32)));
+                            sx = s < p.split ? nx : sx;
+                            sy = s < p.split ? ny : sy;
+                        }
+                        // same arithmetic, same roundings as finish_receiver / finish_kernel
+                        float2 a = make_float2(sx, sy);
+                        if (p.flags & STEP_ACC_IN) {
+                            a.x = __fadd_rn(a0.x, a.x);
+                            a.y = __fadd_rn(a0.y, a.y);
+                        }
+                        p.acc[i] = a;
+                        if (p.flags & STEP_NO_FINALIZE) continue;
+                        float2 v = v0, q = q0;
+                        v.x = __fadd_rn(v.x, __fmul_rn(a.x, dt));
+                        v.y = __fadd_rn(v.y, __fmul_rn(a.y, dt));
+                        q.x = __fadd_rn(q.x, __fmul_rn(v.x, dt));
+                        q.y = __fadd_rn(q.y, __fmul_rn(v.y, dt));
+                        p.vel[i] = v;
+                        p.pos_out[i] = q;
+                        if (i < p.n_mirror) p.mirror[i] = q;
+                    }
                 }
             }
+        }
+
+        if constexpr (!PERSIST) {
+            break;
+        } else {
+            // the next work item of this workgroup; the LDS reduction buffers are reused, so every wave must be done with them
+            // (readfirstlane: the compiler must keep seeing wave-uniform values, or the source loads stop being scalar loads)
+            item = __builtin_amdgcn_readfirstlane(item + gridDim.x);
+            if (item >= n_tiles * p.split) break;
+            tile_x = __builtin_amdgcn_readfirstlane(item % n_tiles);
+            part_y = __builtin_amdgcn_readfirstlane(item / n_tiles);
+            __syncthreads();
         }
     }
 }
@@ -877,6 +929,16 @@ const void *pick_fused(int k, int w) {
     return nullptr;
 }
 
+// persistent launches (experiment, "persist" hook): scalar-cache route, with and without the fused finish
+template <bool FUSED>
+const void *pick_persist(int k, int w) {
+#define NB_CASE(KK, WW) \
+    if (k == KK && w == WW) return reinterpret_cast<const void *>(&step_kernel<KK, WW, VARIANT_SMEM, FUSED, true>);
+    NB_CASE(1, 4) NB_CASE(1, 8) NB_CASE(1, 16) NB_CASE(2, 4) NB_CASE(2, 8) NB_CASE(2, 16)
+#undef NB_CASE
+    return nullptr;
+}
+
 const void *pick_lane_split(int w, int h) {
 #define NB_CASE(WW, HH) \
     if (w == WW && h == HH) return reinterpret_cast<const void *>(&lane_split_kernel<WW, HH>);
@@ -960,7 +1022,7 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
     // smaller split.  More, shorter workgroups also shrink the launch's ramp-up/ragged-end share.  K = 4 is left out: 71 VGPRs, lower
     // occupancy, never faster (profiles/r01_sweep4_shapes_by_n.txt).
     if (compute_units <= 0) compute_units = 256;
-    if (want.lanes == 0 && want.k == 0 && want.w == 0 && want.split == 0 && want.unit == 0 && want.variant == VARIANT_SMEM) {
+    if (want.lanes == 0 && want.k == 0 && want.w == 0 && want.split == 0 && want.unit == 0 && want.persist <= 1 && want.variant == VARIANT_SMEM) {
         // everything on auto (an explicit LDS-tile route or shape knob asks for the classic kernel)
         int w = 16;
         const int lanes = lane_split_rule(n_recv, n_src, &w);
@@ -979,6 +1041,7 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
         sh.split = 1;
         sh.unit = 8;
         sh.variant = VARIANT_LDS;
+        sh.persist = 0;
         return sh;
     }
     if (want.variant == VARIANT_LDS) want.unit = CHUNK;  // the LDS route stages whole 64-source tiles, whatever was asked
@@ -1047,19 +1110,29 @@ LaunchShape choose_shape(LaunchShape want, uint32_t n_recv, uint32_t n_src, int 
 }
 
 // NB_HASH_ON
+bool shape_is_persistent(LaunchShape s) { return s.persist > 1 && s.lanes <= 1 && s.variant == VARIANT_SMEM && s.w >= 4 && s.k <= 2; }
+
 const void *step_kernel_fn(LaunchShape s) {
     if (s.lanes > 1) return pick_lane_split(s.w, s.lanes);
+    if (shape_is_persistent(s)) return pick_persist<false>(s.k, s.w);
     return s.variant == VARIANT_SMEM ? pick<VARIANT_SMEM>(s.k, s.w) : pick<VARIANT_LDS>(s.k, s.w);
 }
 
 const void *step_kernel_fused_fn(LaunchShape s) {
     if (s.lanes > 1 || s.variant != VARIANT_SMEM) return nullptr;
+    if (shape_is_persistent(s)) return pick_persist<true>(s.k, s.w);
     return pick_fused(s.k, s.w);
 }
 
 dim3 step_grid(LaunchShape s, uint32_t n_recv) {
     if (s.lanes > 1) return dim3((n_recv + WAVE / s.lanes - 1) / (WAVE / s.lanes), 1);
-    return dim3((n_recv + WAVE * s.k - 1) / (WAVE * s.k), s.split > 1 ? s.split : 1);
+    const uint32_t tiles = (n_recv + WAVE * s.k - 1) / (WAVE * s.k), parts = s.split > 1 ? s.split : 1;
+    if (shape_is_persistent(s)) {
+        // `persist` work items (tile, part) per workgroup, walked with a stride of the grid size
+        const uint64_t items = (uint64_t)tiles * parts;
+        return dim3((uint32_t)((items + (uint32_t)s.persist - 1) / (uint32_t)s.persist), 1);
+    }
+    return dim3(tiles, parts);
 }
 
 size_t step_lds_bytes(LaunchShape s, uint32_t n_src) {

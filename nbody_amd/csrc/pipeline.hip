@@ -263,7 +263,7 @@ SimPipeline *CreateSimPipelineShardedDirect(WorldData data, int rank, int nranks
 }
 
 void nb_hip_plan_launch(uint32_t n_recv, uint32_t n_src, int compute_units, int *k, int *w, int *split, uint32_t *workgroups) {
-    const nb::LaunchShape sh = nb::choose_shape({0, 0, nb::VARIANT_SMEM, 0, 0, 1}, n_recv, n_src, compute_units);
+    const nb::LaunchShape sh = nb::choose_shape({0, 0, nb::VARIANT_SMEM, 0, 0, 1, 0}, n_recv, n_src, compute_units);
     if (k) *k = sh.k;
     if (w) *w = sh.w;
     if (split) *split = sh.split;
@@ -281,12 +281,12 @@ int nb_hip_plan_launch_lanes(uint32_t n_recv, uint32_t n_src, int *w) {
 }
 
 int nb_hip_plan_fused_finish(uint32_t n_recv, uint32_t n_src, int compute_units) {
-    const nb::LaunchShape sh = nb::choose_shape({0, 0, nb::VARIANT_SMEM, 0, 0, 1}, n_recv, n_src, compute_units);
+    const nb::LaunchShape sh = nb::choose_shape({0, 0, nb::VARIANT_SMEM, 0, 0, 1, 0}, n_recv, n_src, compute_units);
     return sh.split > 1 && nb_hip_plan_launch_lanes(n_recv, n_src, nullptr) <= 1 && fused_finish_rule(n_recv, n_src) ? 1 : 0;
 }
 
 int nb_hip_plan_launch_unit(uint32_t n_recv, uint32_t n_src, int compute_units) {
-    return nb::choose_shape({0, 0, nb::VARIANT_SMEM, 0, 0, 1}, n_recv, n_src, compute_units).unit;
+    return nb::choose_shape({0, 0, nb::VARIANT_SMEM, 0, 0, 1, 0}, n_recv, n_src, compute_units).unit;
 }
 
 int nb_hip_local_group_create(WorldData data, int nranks, SimPipeline **out) {
@@ -653,6 +653,10 @@ int nb_hip_tune(SimPipeline *s, const char *key, int value) {
             s->graphs.clear();
         }
         s->fused_finish = value;
+    } else if (!strcmp(key, "persist")) {
+        NB_ASSERT(value >= 0 && value <= 64, "persist must be 0 (classic) .. 64 work items per workgroup, got %d", value);
+        old = s->want_persist;
+        s->want_persist = value;
     } else if (!strcmp(key, "passes")) {
         NB_ASSERT(value >= 0 && value <= 64, "passes must be 0 (auto) .. 64, got %d", value);
         old = s->want_passes;

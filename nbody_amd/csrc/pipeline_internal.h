@@ -149,7 +149,7 @@ struct StepGraph {
     std::vector<hipGraphNode_t> nodes;  // one kernel node per launch, in order
     std::vector<nb::StepParams> params; // what each node currently holds
     int phase = -1;                     // which pos buffer the chain reads first
-    nb::LaunchShape shape = {0, 0, 0, 0, 0, 0};
+    nb::LaunchShape shape = {0, 0, 0, 0, 0, 0, 0};
     uint64_t last_use = 0;              // for eviction: the cache holds at most GRAPH_CACHE_MAX chains
 };
 
@@ -257,8 +257,9 @@ struct SimPipeline {
     std::vector<uint32_t> seen_chains;                  // chain lengths already run once as plain launches
     int want_passes = 0;  // source passes per step (0 = auto: keep each pass's sources within one XCD's L2)
     double first_gather_ms = 0.0;  // sharded: device time of the probe all-gather at creation (includes lazy setup)
-    nb::LaunchShape last_shape = {0, 0, 0, 0, 0, 0};
+    nb::LaunchShape last_shape = {0, 0, 0, 0, 0, 0, 0};
     int want_unit = 0;  // source-slice granule: 0 = auto, else 64 / 32 / 16 / 8
+    int want_persist = 0;  // experiment: work items per workgroup of a persistent launch (0 / 1 = classic)
     int want_lanes = 0; // lane groups per wave: 0 = auto, 1 = never, 2 / 4 = lane-split kernel (kernels.h LaunchShape::lanes)
     uint32_t last_groups = 0;
     uint32_t fused_steps = 0;   // steps the last update ran inside fused (one-launch) chains

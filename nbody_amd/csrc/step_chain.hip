@@ -60,7 +60,7 @@ void destroy_graph(StepGraph &g) {
 }
 
 nb::LaunchShape resolve_shape(SimPipeline *s) {
-    nb::LaunchShape want = {s->want_k, s->want_w, s->want_variant, s->want_split, s->want_unit, s->want_lanes};
+    nb::LaunchShape want = {s->want_k, s->want_w, s->want_variant, s->want_split, s->want_unit, s->want_lanes, s->want_persist};
     // the model sees one launch: with source passes that is 1/passes of the sources
     nb::StepParams probe;
     memset(&probe, 0, sizeof probe);
@@ -244,7 +244,8 @@ void fill_node(hipKernelNodeParams &kp, void **args, const void *fn, dim3 grid, 
 StepGraph *find_graph(SimPipeline *s, uint32_t n, uint32_t passes, nb::LaunchShape sh, int phase) {
     for (auto &c : s->graphs)
         if (c.n == n && c.passes == passes && c.phase == phase && c.shape.k == sh.k && c.shape.w == sh.w &&
-            c.shape.variant == sh.variant && c.shape.split == sh.split && c.shape.unit == sh.unit && c.shape.lanes == sh.lanes)
+            c.shape.variant == sh.variant && c.shape.split == sh.split && c.shape.unit == sh.unit && c.shape.lanes == sh.lanes &&
+            c.shape.persist == sh.persist)
             return &c;
     return nullptr;
 }
@@ -321,7 +322,7 @@ bool wants_fused_chain(const SimPipeline *s) {
     if (s->fused_chain == 1) return true;
     // an explicit k / w / split / unit / passes / lanes / route asks for the per-step kernel (choose_shape treats them so too)
     const bool shape_on_auto = s->want_k == 0 && s->want_w == 0 && s->want_split == 0 && s->want_unit == 0 && s->want_passes == 0 &&
-                               s->want_lanes == 0 && s->want_variant == nb::VARIANT_SMEM;
+                               s->want_lanes == 0 && s->want_persist == 0 && s->want_variant == nb::VARIANT_SMEM;
     return shape_on_auto && s->n_real <= CHAIN_AUTO_MAX_RECV && (double)s->n_real * (double)(s->n_src ? s->n_src : 1) <= CHAIN_MAX_PAIRS;
 }
 
@@ -343,7 +344,7 @@ void enqueue_fused(SimPipeline *s, uint32_t n) {
         left -= p.steps;
     }
     s->fused_steps = n;
-    s->last_shape = {2, (int)(16u / p.tiles), nb::VARIANT_LDS, 1, 8, 1};   // the per-step shape it is bit-equal to
+    s->last_shape = {2, (int)(16u / p.tiles), nb::VARIANT_LDS, 1, 8, 1, 0};   // the per-step shape it is bit-equal to
     s->last_groups = 1;
 }
 

@@ -1896,3 +1896,33 @@ def test_clock_sampler_runs_beside_the_step_kernels_without_touching_their_resul
     t0 = time.perf_counter()
     late = nb.clock_sampler_end()
     assert time.perf_counter() - t0 < 0.2 and 80.0 <= late["span_ms"] <= 140.0, late
+
+
+def test_persistent_launch_equals_the_classic_launch():
+    """The persistent-launch experiment kernel (tuning hook "persist"; closed: slower at every size,
+    profiles/r05_persist_probe.txt): a launch of 1/P as many workgroups whose waves walk P (tile, part) work items each runs,
+    per item, the code a classic workgroup runs -- same bits as the classic launch, with the finish kernel and with the fused
+    finish, as plain launches and inside a hipGraph; and the classic launch of that state is what the oracle checks."""
+    _, part, m = bench_universe(10000)
+    base = run(part, m, 12, 0.01, graph=0)
+    sim = nb.SimPipeline(10000, m)
+    sim.set_data(part)
+    sim.update(1, 0.01)
+    shape = sim.launch_shape()
+    one = sim.get_data()
+    sim.close()
+    check_one_step(one, part, m, 0.01)
+    fixed = {k: shape[k] for k in ("k", "w", "split", "unit")}
+    assert run(part, m, 1, 0.01, persist=2, **fixed).tobytes() == one.tobytes()
+    assert shape["split"] > 1 and shape["lanes"] == 1
+    for persist in (2, 3, 7):
+        for fused in (0, 1):
+            for graph in (0, 1):
+                got = run(part, m, 12, 0.01, graph=graph, fused_finish=fused, persist=persist, **fixed)
+                assert got.tobytes() == base.tobytes(), (persist, fused, graph)
+    sim = nb.SimPipeline(10000, m)
+    sim.configure(persist=2, **fixed)
+    sim.set_data(part)
+    sim.update(1, 0.01)
+    assert sim.launch_shape()["workgroups"] == (shape["workgroups"] + 1) // 2
+    sim.close()

@@ -96,8 +96,9 @@ def test_step_kernels_fit_the_occupancy_the_launch_bounds_promise(isa):
         assert scratch == 0, f"{name}: {scratch} bytes of scratch (spills)"
         assert sgpr <= 102, f"{name}: {sgpr} SGPRs"
     # the default (scalar-cache) route keeps the asm body's footprint: well under the limit
-    smem = [v for n, _, _, v in step if re.search(r"ELi1E(Lb[01]E)?EEvNS_10StepParamsE$", n)]
-    assert smem and max(smem) <= 48, smem
+    # (template arguments: K, W, VARIANT = 1, FUSED, PERSIST; the persistent experiment kernels may use more, within 64)
+    smem = [v for n, _, _, v in step if re.search(r"ELi1ELb[01]ELb0EEEvNS_10StepParamsE$", n)]
+    assert len(smem) >= 14 and max(smem) <= 48, smem
 
 
 def test_interaction_body_is_the_twelve_instruction_sequence(isa):
@@ -158,9 +159,11 @@ def test_fused_finish_tail_uses_agent_scope_accesses_and_leaves_the_other_kernel
     `buffer_inv`, the L2 write-back that made round 1's first version 5-13x slower).  The unfused instantiations contain
     none of it: their code is what it was."""
     fn = functions(isa)
-    fused = {n: b for n, b in fn.items() if "step_kernel" in n and "Lb1EEEv" in n}
-    plain = {n: b for n, b in fn.items() if "step_kernel" in n and "Lb0EEEv" in n}
-    assert len(fused) == 6 and len(plain) >= 16
+    # template arguments <K, W, VARIANT, FUSED, PERSIST>: ...Lb<FUSED>ELb<PERSIST>EEEv; the persistent experiment kernels
+    # (PERSIST = 1) carry the same tail and are held to the same rules
+    fused = {n: b for n, b in fn.items() if "step_kernel" in n and re.search(r"Lb1ELb[01]EEEv", n)}
+    plain = {n: b for n, b in fn.items() if "step_kernel" in n and re.search(r"Lb0ELb[01]EEEv", n)}
+    assert len(fused) == 12 and len(plain) >= 22
     for name, body in fused.items():
         text = "\n".join(body)
         assert len(re.findall(r"global_store_dwordx2 .* sc1", text)) >= 1, name
