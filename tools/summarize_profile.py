@@ -77,6 +77,13 @@ for f in files:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             agg["_dur_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 mean = {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
 lines.append("")
 lines.append(f"== rocprofv3 --pmc <counters> --kernel-trace, one pass per counter group; per launch (mean) of {headline} ==")
 for k in sorted(mean):
@@ -85,8 +92,12 @@ for k in sorted(mean):
 summary = {"tag": tag, "step_kernel_avg_ns_stats_pass": step_avg_ns}
 if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
     dur = mean["_dur_ns"] * 1e-9
-    fetch_raw = mean["FETCH_SIZE"] * 1024.0      # rocprofv3 reports KiB
-    write = mean["WRITE_SIZE"] * 1024.0
+    # the MEDIAN launch: one launch in ten can read three times the usual (round 5: 111 MB beside nine launches of 34-35 MB),
+    # and a per-launch figure should describe the launch, not that one
+    fetch_raw = median(agg["FETCH_SIZE"]) * 1024.0      # rocprofv3 reports KiB
+    write = median(agg["WRITE_SIZE"]) * 1024.0
+    lines.append("")
+    lines.append("FETCH_SIZE per launch, KiB: " + " ".join(f"{v:.0f}" for v in agg["FETCH_SIZE"]) + f"   (median {median(agg['FETCH_SIZE']):.0f}, mean {mean['FETCH_SIZE']:.0f})")
     # MI355X_MICROARCH.md "HBM": on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced streams;
     # doubling is the prescribed correction and an upper bound for this kernel's 64-B scalar-cache line fills
     fetch_corr = 2.0 * fetch_raw
@@ -96,8 +107,7 @@ if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
         "hbm_GBps": (fetch_corr + write) / dur / 1e9,
         "launch_seconds_pmc_pass": dur,
     })
-    lines.append("")
-    lines.append(f"memory-side traffic per launch: fetch {fetch_raw/1e6:.1f} MB raw ({fetch_corr/1e6:.1f} MB with the gfx950 x2 correction), "
+    lines.append(f"memory-side traffic per launch (median): fetch {fetch_raw/1e6:.1f} MB raw ({fetch_corr/1e6:.1f} MB with the gfx950 x2 correction), "
                  f"write {write/1e6:.1f} MB  ->  {(fetch_corr + write)/dur/1e9:.1f} GB/s of ~8000 GB/s HBM peak")
 if "GRBM_GUI_ACTIVE" in mean:
     clk = mean["GRBM_GUI_ACTIVE"] / 8.0 / (mean["_dur_ns"] * 1e-9)
@@ -141,7 +151,7 @@ if "hbm_bytes_per_launch" in summary:
     json.dump({"hbm_bytes_per_launch": summary["hbm_bytes_per_launch"], "fetch_bytes_raw": summary["fetch_bytes_raw"],
                "write_bytes": summary["write_bytes"], "source": f"profiles/{tag}_pmc_summary.json",
                "n": 1 << 20, "kernel_sources_sha256": bench.kernel_sources_sha(), "launch": launch,
-               "note": "hbm_bytes_per_launch = FETCH_SIZE*1024*2 + WRITE_SIZE*1024, mean per step_kernel launch, N=2^20.  The x2 is "
+               "note": "hbm_bytes_per_launch = FETCH_SIZE*1024*2 + WRITE_SIZE*1024, median step_kernel launch of the PMC passes, N=2^20.  The x2 is "
                        "MI355X_MICROARCH.md's gfx950 correction, calibrated on 16-B-per-lane coalesced streaming loads; this "
                        "kernel loads 8-B float2 / 4-B float per lane plus 64-B scalar-cache lines (uncalibrated widths), so the "
                        "corrected figure is an upper bound and fetch_bytes_raw + write_bytes a lower bound.  Run "
