@@ -556,8 +556,9 @@ def parse_args(argv=None):
                     help="rehearsal only (host transport): the all-gather callback never returns during this leg "
                          "(overlap | sharded_graph | config5), to exercise the deadline path")
     ap.add_argument("--crash-leg", default=None,
-                    help="rehearsal only (host transport): rank 0 abort()s inside this leg's all-gather, to exercise the "
-                         "last-gasp line")
+                    help="rehearsal only: rank 0 abort()s inside this leg (N > 1, host transport: in the leg's all-gather; one GPU: "
+                         "at the start of the leg -- 'clock probe', 'parity stamp', 'repeats', 'clock sampler leg', 'alt_lds', "
+                         "'extra_configs C2/C3/N2/C1', 'extra_configs S2/S4/S8/C5S8'), to exercise the last-gasp line")
     ap.add_argument("--rehearse-rccl-failure", action="store_true",
                     help="rehearsal only: in an rccl attempt the last rank leaves with exit code 3 right after the rendezvous, like the "
                          "library's watchdog does when ncclCommInitRank never completes -- exercises --transport auto's fallback")
@@ -769,15 +770,7 @@ def worker_main(args):
         elapsed = timed_leg(sim, args.steps, args.warmup)
         steps_done = args.warmup + args.steps
         kernel_ms, launches = sim.last_step_ms()
-        # the clock the chip holds for this kind of work, asked right after the timed steps and outside them: a separate
-        # probe kernel with the step kernels' instruction mix (include/nbody_hip.h nb_hip_probe_clock); the product
-        # kernels carry no stamps
-        clock = None
-        if rank == 0 and not args.no_clock_probe:
-            try:
-                clock = nb.probe_clock(40.0)
-            except Exception as e:  # pragma: no cover - diagnostic only
-                clock = {"error": str(e)}
+        clock = None   # single GPU: the clock probe runs once the line below is in hand (so does the parity stamp)
         finish_launches = sim.finish_launches()
         shape = sim.launch_shape()
         info = nb.device_info()
@@ -788,8 +781,6 @@ def worker_main(args):
             extras["rccl"] = comm_evidence(sim)
             d = sharded_detail(sim, args.steps)
             extras["comm_ms_per_step"], extras["kernel_ms_per_step"] = d["comm_ms_per_step"], d["kernel_ms_per_step"]
-        elif not args.no_parity:
-            extras["parity"] = parity_stamp(sim, mass_len)   # after the timed call, outside it
 
     # ---- the JSON dict: complete from here on; later legs only add keys -----------------------------------------
     out = {}
@@ -883,6 +874,33 @@ def worker_main(args):
         if rank == 0:
             with out_lock:
                 out[key] = val
+
+    # Single GPU: from here on every further leg -- clock probe, parity stamp, repeats, the clock-sampler leg, the LDS
+    # route, extra_configs -- runs with the line in hand: the library's error convention is abort(), and a fatal signal
+    # inside any of them still writes the headline (plus "extras_aborted": which leg) through the C-level handler.
+    solo_gasp = LastGasp(json_fd) if (rank == 0 and not sharded and not args.dry_run) else None
+
+    def solo_leg(name):
+        if solo_gasp:
+            with out_lock:
+                solo_gasp.arm((json.dumps(dict(out, extras_aborted=f"{name} (fatal signal)")) + "\n").encode())
+            if args.crash_leg == name:
+                os.abort()   # rehearsal of a leg that dies by the library's abort() convention (--crash-leg)
+
+    if not sharded and not args.dry_run and rank == 0:
+        if not args.no_clock_probe:
+            # the clock the chip holds for the interaction statement alone, asked right after the timed steps and outside
+            # them: a separate probe kernel (include/nbody_hip.h nb_hip_probe_clock); the product kernels carry no stamps
+            solo_leg("clock probe")
+            try:
+                clock = nb.probe_clock(40.0)
+            except Exception as e:  # pragma: no cover - diagnostic only
+                clock = {"error": str(e)}
+            with out_lock:
+                out["roofline"].update(held_clock_fields(clock, None, per_launch_s, launch_interactions, info, achieved_tflops))
+        if not args.no_parity:
+            solo_leg("parity stamp")
+            put("parity", parity_stamp(sim, mass_len))   # after the timed call, outside it
 
     # ---- optional legs ------------------------------------------------------------------------------------------
     if sharded:
@@ -1011,9 +1029,11 @@ def worker_main(args):
                 gasp.disarm()
     elif not sharded and not args.no_extras and not args.dry_run:
         # same K steps twice more (run-to-run spread), then the LDS-tile route of the north star on the same chain
+        solo_leg("repeats")
         put("repeat_ms_per_step", [timed_leg(sim, args.steps, 0) / args.steps * 1e3 for _ in range(2)])
         if not args.no_clock_probe and rank == 0:
             # the clock the chip holds UNDER THE STEP KERNEL: the same K steps once more with the sampler running beside them
+            solo_leg("clock sampler leg")
             try:
                 nb.clock_sampler_begin(0.5, 3.0 * elapsed * 1e3 + 500.0)
                 e_clk = timed_leg(sim, args.steps, 0)
@@ -1027,6 +1047,7 @@ def worker_main(args):
                     out["roofline"].update(held_clock_fields(clock, sampled, per_launch_s, launch_interactions, info, achieved_tflops))
             except Exception as e:  # pragma: no cover - diagnostic only
                 put("clock_sampler_error", str(e))
+        solo_leg("alt_lds")
         sim.configure(variant=0)
         e_lds = timed_leg(sim, args.steps, 2)
         lds_ms, lds_launches = sim.last_step_ms()
@@ -1043,26 +1064,18 @@ def worker_main(args):
         sim.close()
         sim = None
         if not args.all_massive and args.n == N_PARTICLES and not args.no_extra_configs:
-            # the library's error convention is abort(): from here on a fatal signal still writes the line in hand
-            gasp = LastGasp(json_fd) if rank == 0 else None
-
-            def arm(name):
-                if gasp:
-                    with out_lock:
-                        gasp.arm((json.dumps(dict(out, extras_aborted=f"{name} (fatal signal)")) + "\n").encode())
-
-            arm("extra_configs C2/C3/N2/C1")
+            solo_leg("extra_configs C2/C3/N2/C1")
             configs = single_gpu_configs(nb, stamp=not args.no_parity)
             put("extra_configs", configs)
-            arm("extra_configs S2/S4/S8/C5S8")
+            solo_leg("extra_configs S2/S4/S8/C5S8")
             try:
                 configs.extend(shard_scaling_configs(nb, elapsed / args.steps * 1e3, stamp=not args.no_parity, n5=args.n5))
             except Exception as e:  # pragma: no cover - diagnostic only
                 configs.append({"config": "S2/S4/S8/C5S8", "error": str(e)})
-            if gasp:
-                gasp.disarm()
     if sim is not None:
         sim.close()
+    if solo_gasp:
+        solo_gasp.disarm()
 
     emit()
 

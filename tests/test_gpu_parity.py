@@ -1926,3 +1926,20 @@ def test_persistent_launch_equals_the_classic_launch():
     sim.update(1, 0.01)
     assert sim.launch_shape()["workgroups"] == (shape["workgroups"] + 1) // 2
     sim.close()
+
+
+@pytest.mark.parametrize("leg", ["clock probe", "repeats", "extra_configs C2/C3/N2/C1"])
+def test_single_gpu_bench_line_survives_a_leg_that_aborts(leg):
+    """The driver's own command (`python bench.py`, one GPU): every leg after the headline -- clock probe, parity stamp,
+    repeats, the clock-sampler leg, the LDS route, extra_configs -- runs with the line in hand.  A leg that dies by the
+    library's error convention (print + abort(), reference src/lib/util.h:17-29) still leaves the headline on stdout, once,
+    with "extras_aborted" naming the leg, and the run does not report success."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(nb.ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--crash-leg", leg], capture_output=True, text=True, timeout=600, cwd=nb.ROOT)
+    assert r.returncode == 6, (r.returncode, r.stderr[-1500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    out = json.loads(lines[0])
+    assert out["extras_aborted"] == f"{leg} (fatal signal)" and out["value"] > 1e12 and out["roofline"]["frac"] > 0.3
+    assert ("parity" in out) == (leg != "clock probe")      # legs that finished before the abort are on the line
