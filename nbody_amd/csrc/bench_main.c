@@ -31,7 +31,11 @@
  * Several GPUs (SURVEY.md section 8f rank 1 `--gpus`, 8e): one process per GPU, host code in C, no Python, no torch.
  *   --gpus P           fork P ranks BEFORE anything touches HIP; rank r drives device r; the ranks share one
  *                      anonymous MAP_SHARED page (rank_page.h) for barriers, the max-over-ranks time and RCCL's unique id
- *   --transport T      rccl (default): CreateWorldSharded, per-step in-place ncclAllGather over xGMI inside the library;
+ *   --transport T      auto (default): rccl, and if any rank of that attempt ends with an error (RCCL that does not come up: the
+ *                      library's watchdog leaves with 3, its error convention with abort(); fewer devices than ranks) the
+ *                      parent -- which never touches the GPU -- forks a FRESH set of ranks over the direct exchange (ipc) and
+ *                      says so on stdout and stderr ("transport_fallback"); nothing is retried inside a process that touched HIP;
+ *                      rccl: CreateWorldSharded, per-step in-place ncclAllGather over xGMI inside the library;
  *                      ipc: CreateWorldShardedDirect -- no RCCL: every rank maps its peers' source arrays (hipIpc handles passed
  *                      through the page) and pushes its slice device-to-device into each after every step (on xGMI one copy per
  *                      link), then ONE host barrier per step at the page; the fallback should RCCL not come up;
@@ -132,7 +136,7 @@ enum { MODE_PLAIN = 0, MODE_OVERLAP = 1, MODE_GRAPH = 2, MODE_COUNT = 3 };
 static const char *const MODE_NAME[MODE_COUNT] = {"plain", "overlap", "graph"};
 
 typedef struct Options {
-    bool use_cpu, use_gpu, own_rng, transport_shm, transport_ipc, force_sharded, selftest_ranks, verify_given, speedup, one_wave;
+    bool use_cpu, use_gpu, own_rng, transport_shm, transport_ipc, transport_auto, force_sharded, selftest_ranks, verify_given, speedup, one_wave;
     /* transport_shm: any host-callback transport (shm or ipc: both need the page's exchange area); transport_ipc: the direct one */
     uint32_t sizes[64];
     uint32_t n_sizes, steps, warmup, galaxies, repeats, verify_steps;
@@ -455,7 +459,7 @@ static int selftest_rank(const Options *o, NbRankPage *pg) {
 }
 
 /* fork the ranks (nothing has touched HIP yet), wait for all of them, end the stragglers once one has failed */
-static int run_ranks(const Options *o) {
+static int run_ranks_once(const Options *o) {
     const int P = o->gpus;
     uint32_t max_n = 0;
     for (uint32_t s = 0; s < o->n_sizes; s++) max_n = o->sizes[s] > max_n ? o->sizes[s] : max_n;
@@ -526,6 +530,30 @@ static int run_ranks(const Options *o) {
     return worst;
 }
 
+/* --transport auto: the RCCL attempt, and if any of its ranks ends with an error a second attempt over the direct exchange
+ * in FRESH processes (this parent never touches HIP, so nothing is retried inside a process that did) */
+static int run_ranks(const Options *o) {
+    if (!o->transport_auto || o->selftest_ranks) return run_ranks_once(o);
+    Options first = *o;
+    first.transport_shm = first.transport_ipc = false;
+    setenv("NB_HIP_COMM_TIMEOUT_S", "75", 0); /* there is a fallback: do not sit out the library's 180 s */
+    const int rc = run_ranks_once(&first);
+    if (rc == 0) return 0;
+    Options second = *o;
+    second.transport_shm = second.transport_ipc = true;
+    second.n_modes = 0;
+    for (int i = 0; i < o->n_modes; i++)
+        if (o->modes[i] != MODE_GRAPH) second.modes[second.n_modes++] = o->modes[i]; /* a host barrier cannot be captured */
+    if (second.n_modes == 0) second.modes[second.n_modes++] = MODE_PLAIN;
+    unsetenv("NB_HIP_COMM_TIMEOUT_S");
+    fprintf(stderr, "nbody-bench: transport_fallback rccl -> ipc: a rank of the RCCL attempt ended with status %d; starting %d fresh rank "
+            "processes over the direct exchange\n", rc, o->gpus);
+    printf("# transport_fallback rccl -> ipc (a rank of the RCCL attempt ended with status %d); what follows is the second attempt: fresh "
+           "rank processes, direct device-to-device exchange\n", rc);
+    fflush(stdout);
+    return run_ranks_once(&second);
+}
+
 static int parse_modes(Options *o, const char *list) {
     o->n_modes = 0;
     char tmp[128];
@@ -544,7 +572,7 @@ int main(int argc, char **argv) {
     Options o;
     memset(&o, 0, sizeof o);
     o.use_cpu = o.use_gpu = true;
-    o.steps = 100, o.warmup = 10, o.galaxies = 2, o.repeats = 1, o.verify_steps = 3;
+    o.steps = 100, o.warmup = 10, o.galaxies = 2, o.repeats = 1, o.verify_steps = 3, o.transport_auto = true;
     o.seed = 11037;
     o.dt = 1.f;
     o.gpus = 1;
@@ -579,8 +607,10 @@ int main(int argc, char **argv) {
             o.own_rng = true;
         } else if (!strcmp(arg, "--gpus") && val) {
             o.gpus = atoi(val), a++;
+        } else if (!strcmp(arg, "--transport") && val && !strcmp(val, "auto")) {
+            o.transport_auto = true, o.transport_ipc = o.transport_shm = false, a++;
         } else if (!strcmp(arg, "--transport") && val && (!strcmp(val, "rccl") || !strcmp(val, "shm") || !strcmp(val, "ipc"))) {
-            o.transport_ipc = !strcmp(val, "ipc"), o.transport_shm = strcmp(val, "rccl") != 0, a++;
+            o.transport_auto = false, o.transport_ipc = !strcmp(val, "ipc"), o.transport_shm = strcmp(val, "rccl") != 0, a++;
         } else if (!strcmp(arg, "--modes") && val) {
             modes = val, a++;
         } else if (!strcmp(arg, "--verify") && val) {
@@ -601,7 +631,7 @@ int main(int argc, char **argv) {
             fprintf(stderr,
                     "usage: %s [--cpu|--gpu] [--n N]... [--steps K] [--warmup W] [--dt DT] [--galaxies G] [--seed S]"
                     " [--own-rng] [--repeats R] [--floor-rate INT_PER_S]\n"
-                    "       [--gpus P [--transport rccl|ipc|shm] [--modes plain,overlap,graph] [--verify K] [--speedup] [--force-sharded] [--one-wave]"
+                    "       [--gpus P [--transport auto|rccl|ipc|shm] [--modes plain,overlap,graph] [--verify K] [--speedup] [--force-sharded] [--one-wave]"
                     " [--wait-timeout S] [--selftest-ranks]]\n",
                     argv[0]);
             return 2;

@@ -1669,8 +1669,27 @@ def test_nbody_bench_c_one_forced_rccl_rank():
 def test_nbody_bench_c_ranks_refuses_rccl_without_enough_devices():
     if nb.device_count() >= 2:
         pytest.skip("more than one GPU here")
-    r = _bench_ranks(["--gpus", "2", "--n", "1200", "--steps", "2"], timeout=120)
-    assert r.returncode != 0 and "needs 2 (one per rank)" in r.stderr
+    r = _bench_ranks(["--gpus", "2", "--transport", "rccl", "--n", "1200", "--steps", "2"], timeout=120)
+    assert r.returncode != 0 and "needs 2 (one per rank)" in r.stderr and "transport_fallback" not in r.stderr
+
+
+def test_nbody_bench_c_falls_back_to_the_direct_exchange_in_fresh_ranks():
+    """nbody-bench --gpus 2 with the default --transport auto on a one-GPU box: the RCCL attempt's ranks end with an error
+    (two ranks, one device), the parent -- which never touches HIP -- forks a FRESH set of ranks over the direct exchange,
+    says so on both streams, and the table of the second attempt is verified against a single-GPU World like any other
+    (the C harness' half; reference shape: one plain command, src/bench.c:41-74)."""
+    import re
+    if nb.device_count() >= 2:
+        pytest.skip("more than one GPU here: the RCCL attempt would succeed")
+    r = _bench_ranks(["--gpus", "2", "--n", "20000", "--steps", "5", "--warmup", "1", "--dt", "0.01"], timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "transport_fallback rccl -> ipc" in r.stderr and "2 ranks, transport ipc" in r.stderr
+    lines = r.stdout.strip().splitlines()
+    mark = next(i for i, l in enumerate(lines) if l.startswith("# transport_fallback rccl -> ipc"))
+    rows = [l.split() for l in lines[mark + 2:]]       # header, then one row per mode (plain, overlap: no captured graph over ipc)
+    assert [(x[0], x[2]) for x in rows] == [("20000", "plain"), ("20000", "overlap")] and all(float(x[5]) > 1e9 for x in rows)
+    v = re.findall(r"verify N=20000 mode=(\w+) steps=3: ranks agree (\w+); vs single GPU: rel_l2_pos ([0-9.e+-]+)", r.stderr)
+    assert [(a, b) for a, b, _ in v] == [("plain", "yes"), ("overlap", "yes")] and all(float(x[2]) <= 1e-6 for x in v)
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(ob.ORACLE_DIR, "_ref", "nbody-bench-ref")),
