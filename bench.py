@@ -932,11 +932,11 @@ def worker_main(args):
             assert p5["src_padded"] >= m5
             put("extra_configs", [] if args.no_extras else [
                 _extra_entry(n, mass_len, 1, 0, args.steps, 0.0, None, world),
-                _extra_entry(n, mass_len, 0, 1, args.steps, 0.0, None, world),
                 _extra_entry(part5.shape[0], m5, 0, 0, 3, 0.0, None, world),
                 _extra_entry(part5.shape[0], m5, 1, 0, 3, 0.0, None, world),
             ] + ([dict(_extra_entry(n, mass_len, 0, 0, args.steps, 0.0, None, world), transport="direct (dry run)")]
-                 if host_gather is None else []))
+                 if host_gather is None else [])
+              + [_extra_entry(n, mass_len, 0, 1, args.steps, 0.0, None, world)])
         else:
             # NOT optional for any N > 1 headline (--no-extras keeps it): every rank must hold the same full state, and it must
             # be the single-GPU state of the same steps -- the check that would catch a stale or torn exchange
@@ -984,24 +984,7 @@ def worker_main(args):
             sim.configure(overlap=1)
             e1 = timed_leg(sim, args.steps, 1)
             extra.append(_extra_entry(n, mass_len, 1, 0, args.steps, e1, sharded_detail(sim, args.steps), world))
-            # north star: "multi-step chains are captured as hipGraph" -- the {kernel, all-gather} x K chain captured
-            # from the stream and replayed (RCCL inside stream capture; a host callback cannot be captured)
-            leg("sharded_graph")
             sim.configure(overlap=0)
-            if host_gather is None:
-                sim.configure(sharded_graph=1)
-                eg = timed_leg(sim, args.steps, args.steps)   # the warm-up call captures and instantiates the chain
-                entry = _extra_entry(n, mass_len, 0, 1, args.steps, eg, None, world)
-                entry["graph_stats"] = sim.graph_stats()
-                extra.append(entry)
-                sim.configure(sharded_graph=0)
-            else:
-                if args.stall_leg == "sharded_graph":
-                    sim.update(1, DT)
-                extra.append(dict(_extra_entry(n, mass_len, 0, 1, args.steps, 0.0, None, world),
-                                  skipped="host transport: a host callback cannot run inside a captured graph"))
-            sim.close()
-            sim = None
             # BASELINE.json config 5: N = 2^22, plain and overlapped (own communicator: a second ncclCommInitRank)
             leg("config5")
             part5, m5 = make_workload(args.n5)
@@ -1013,7 +996,7 @@ def worker_main(args):
                 e5 = timed_leg(sim5, 3, 1)
                 extra.append(_extra_entry(part5.shape[0], m5, ov, 0, 3, e5, sharded_detail(sim5, 3), world))
             sim5.close()
-            # last and least travelled: the direct exchange (no RCCL; slices pushed device-to-device into IPC-mapped peers,
+            # the direct exchange (no RCCL; slices pushed device-to-device into IPC-mapped peers,
             # one barrier per step over the rendezvous link) on the headline workload, for an RCCL-vs-direct comparison
             # from the same command -- only when the run's own transport is RCCL (otherwise the legs above were it)
             if host_gather is None and link_gather is not None:
@@ -1031,6 +1014,24 @@ def worker_main(args):
                                                 if not entry["self_check"]["crossed_devices"] else "FAILED across devices")
                 extra.append(entry)
                 simd.close()
+            # LAST, because it is the least-travelled path of the stack and a stall here must not cost the legs above:
+            # north star: "multi-step chains are captured as hipGraph" -- the {kernel, all-gather} x K chain captured
+            # from the stream and replayed (RCCL inside stream capture; a host callback cannot be captured)
+            leg("sharded_graph")
+            if host_gather is None:
+                sim.configure(sharded_graph=1)
+                eg = timed_leg(sim, args.steps, args.steps)   # the warm-up call captures and instantiates the chain
+                entry = _extra_entry(n, mass_len, 0, 1, args.steps, eg, None, world)
+                entry["graph_stats"] = sim.graph_stats()
+                extra.append(entry)
+                sim.configure(sharded_graph=0)
+            else:
+                if args.stall_leg == "sharded_graph":
+                    sim.update(1, DT)
+                extra.append(dict(_extra_entry(n, mass_len, 0, 1, args.steps, 0.0, None, world),
+                                  skipped="host transport: a host callback cannot run inside a captured graph"))
+            sim.close()
+            sim = None
             if guard:
                 guard.disarm()
             if gasp:

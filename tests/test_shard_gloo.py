@@ -56,11 +56,12 @@ def test_bench_multi_rank_control_flow_dry_run(world, rendezvous):
         assert set(out[key]) == {"min", "max"}
     assert out["self_check"]["ranks_agree"] is True          # every rank generated the same initial conditions
     extra = out["extra_configs"]
-    # overlapped step, the chain captured as a hipGraph (north star), then config 5 plain and overlapped
+    # overlapped step, config 5 plain and overlapped, the direct exchange on the headline workload, and LAST -- a stall there
+    # must not cost the others -- the chain captured as a hipGraph (north star; RCCL inside stream capture)
     assert [(e["overlap"], e["sharded_graph"], "N=65536" in e["workload"]) for e in extra] == \
-        [(1, 0, True), (0, 1, True), (0, 0, False), (1, 0, False), (0, 0, True)]
-    assert all("N=131072" in e["workload"] for e in extra[2:4])
-    assert extra[4]["transport"].startswith("direct")       # RCCL runs end with the direct exchange on the headline workload
+        [(1, 0, True), (0, 0, False), (1, 0, False), (0, 0, True), (0, 1, True)]
+    assert all("N=131072" in e["workload"] for e in extra[1:3])
+    assert extra[3]["transport"].startswith("direct")
     for e in extra:
         assert set(e) >= {"workload", "overlap", "sharded_graph", "steps", "ms_per_step", "steps_per_sec", "value", "unit",
                           "kernel_ms_per_step", "comm_ms_per_step"}
