@@ -1064,6 +1064,8 @@ def test_gpu_versus_the_avx_path_at_every_baseline_size(n):
     print(gpu_vs_avx.line(r))
     assert r["gpu_avx_max"] <= bound, r
     assert r["gpu_f64_max"] <= r["avx_f64_max"]              # the difference is carried by the AVX order's error
+    # ... at the first step and at every later one, each from the GPU's own state (float64 is the tie-breaker)
+    assert r["later_steps_tie_break_holds"] and r["later_steps_gpu_f64_max"] <= r["later_steps_avx_f64_min"], r
     assert r["rel_displacement"] <= 5e-5, r                   # measured <= 1.5e-5; the stated multi-step tolerance is 1e-4
     assert r["rel_l2_vel"] <= 1e-4 and r["rel_l2_pos"] <= 1e-6 and r["static_equal"]
 

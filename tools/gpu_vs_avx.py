@@ -51,9 +51,20 @@ def measure(n, steps, samples=2000, **knobs):
     one = sim.get_data()
     shape = sim.launch_shape()
     gpu = one[idx, 4:6].astype(np.float64)
-    if steps > 1:
-        sim.update(steps - 1, DT)
-    got = sim.get_data()
+    # every further step is tie-broken against float64 too, from the GPU's OWN state at the start of the step:
+    # the sampled accelerations the step stored must be closer to the float64 sum of that state than the AVX order's are
+    tie = []
+    state = one
+    for _ in range(steps - 1):
+        sim.update(1, DT)
+        nxt = sim.get_data()
+        a64, mg = ob.acc_f64_subset(state, m, idx)
+        a_avx = ob.acc_avx_subset(state, m, idx).astype(np.float64)
+        g = float((np.abs(nxt[idx, 4:6].astype(np.float64) - a64) / mg).max())
+        a = float((np.abs(a_avx - a64) / mg).max())
+        tie.append((g, a))
+        state = nxt
+    got = state
     sim.close()
     t0 = time.perf_counter()
     want = ob.step(part, m, DT, steps, kind="avx")
@@ -74,6 +85,10 @@ def measure(n, steps, samples=2000, **knobs):
     out["rel_l2_vel"] = float(np.linalg.norm(got[:, 2:4].astype(np.float64) - vw) / np.linalg.norm(vw))
     out["rel_l2_pos"] = float(np.linalg.norm(got[:, 0:2].astype(np.float64) - want[:, 0:2]) / np.linalg.norm(want[:, 0:2].astype(np.float64)))
     out["static_equal"] = bool(np.array_equal(got[:, 6:8], want[:, 6:8]))
+    # later steps: worst GPU-f64 and the AVX-f64 of the same step, as fractions of sum|contrib| (empty when steps == 1)
+    out["later_steps_gpu_f64_max"] = max((g for g, _ in tie), default=0.0)
+    out["later_steps_avx_f64_min"] = min((a for _, a in tie), default=0.0)
+    out["later_steps_tie_break_holds"] = all(g <= a for g, a in tie)
     return out
 
 
@@ -82,7 +97,9 @@ def line(r):
             f"  one step, {r['samples']} receivers, |d acc| / sum|contrib|: GPU-AVX max {r['gpu_avx_max']:.2e} rms {r['gpu_avx_rms']:.2e} | "
             f"GPU-f64 max {r['gpu_f64_max']:.2e} rms {r['gpu_f64_rms']:.2e} | AVX-f64 max {r['avx_f64_max']:.2e} rms {r['avx_f64_rms']:.2e}\n"
             f"  {r['steps']} steps at dt={DT} vs the AVX stepper ({r['cpu_seconds']:.1f} s of host cores): rel_displacement {r['rel_displacement']:.2e}, "
-            f"rel L2 vel {r['rel_l2_vel']:.2e}, rel L2 pos {r['rel_l2_pos']:.2e}, mass/radius equal {r['static_equal']}")
+            f"rel L2 vel {r['rel_l2_vel']:.2e}, rel L2 pos {r['rel_l2_pos']:.2e}, mass/radius equal {r['static_equal']}\n"
+            f"  float64 tie-break at every later step, from the GPU's own state: worst GPU-f64 {r['later_steps_gpu_f64_max']:.2e} vs smallest "
+            f"AVX-f64 {r['later_steps_avx_f64_min']:.2e} of sum|contrib| -> {'holds' if r['later_steps_tie_break_holds'] else 'FAILS'}")
 
 
 if __name__ == "__main__":
