@@ -87,6 +87,7 @@ HIP_API = {
 # nbody_amd/csrc/nbody_hip_tuning.h: test and tooling hooks, exported by the library but NOT part of the C-ABI
 TUNE_API = {
     "nb_hip_tune": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "nb_hip_tuning_build": (C.c_int, []),
     "nb_hip_launch_unit": (C.c_int, [C.c_void_p]),
     "nb_hip_last_fused_steps": (C.c_uint32, [C.c_void_p]),
     "nb_hip_launch_lanes": (C.c_int, [C.c_void_p]),

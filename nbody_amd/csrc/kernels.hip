@@ -930,12 +930,19 @@ const void *pick_fused(int k, int w) {
 }
 
 // persistent launches (experiment, "persist" hook): scalar-cache route, with and without the fused finish
+// (built only with make TUNING=1: the experiment lost at every size, profiles/r05_persist_probe.txt, and twelve more
+// instantiations of the step kernel are not worth carrying in the library that ships)
 template <bool FUSED>
 const void *pick_persist(int k, int w) {
+#ifdef NB_TUNING_SHAPES
 #define NB_CASE(KK, WW) \
     if (k == KK && w == WW) return reinterpret_cast<const void *>(&step_kernel<KK, WW, VARIANT_SMEM, FUSED, true>);
     NB_CASE(1, 4) NB_CASE(1, 8) NB_CASE(1, 16) NB_CASE(2, 4) NB_CASE(2, 8) NB_CASE(2, 16)
 #undef NB_CASE
+#else
+    (void)k;
+    (void)w;
+#endif
     return nullptr;
 }
 

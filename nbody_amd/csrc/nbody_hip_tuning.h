@@ -40,9 +40,15 @@ extern "C" {
  *               row were each followed by a Get into the noted array)
  *   "zero_copy_upload"  1 (default) = SetSimulationData from the noted, page-locked array lets the split kernel read the
  *               records over PCIe itself; 0 = DMA copy into device staging, then the kernel
+ *   "persist"   TUNING=1 builds only: work items (receiver tile, source part) per workgroup of a persistent launch
  * Returns the previous value; aborts on an unknown key or value.
  */
 int nb_hip_tune(SimPipeline *sim, const char *key, int value);
+
+/* 1 when the library was built with make TUNING=1: the launch shapes the cost model never picks (K = 4, W = 2), the
+ * persistent-launch experiment kernels ("persist" hook: items per workgroup, 0 / 1 = classic; closed in round 5, slower at
+ * every size) and the NB_HIP_* environment presets of the hooks above exist in such builds only. */
+int nb_hip_tuning_build(void);
 
 /* Steps of the last update that ran inside one-workgroup chain launches ("fused_chain"). */
 uint32_t nb_hip_last_fused_steps(const SimPipeline *sim);

@@ -616,6 +616,14 @@ int nb_hip_configure(SimPipeline *s, const char *key, int value) {
 }
 
 // Test / tooling hooks (nbody_hip_tuning.h): not part of the C-ABI.
+int nb_hip_tuning_build(void) {
+#ifdef NB_TUNING_SHAPES
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int nb_hip_tune(SimPipeline *s, const char *key, int value) {
     NB_ASSERT(s != nullptr && key != nullptr, "NULL argument");
     int old = 0;
@@ -655,6 +663,9 @@ int nb_hip_tune(SimPipeline *s, const char *key, int value) {
         s->fused_finish = value;
     } else if (!strcmp(key, "persist")) {
         NB_ASSERT(value >= 0 && value <= 64, "persist must be 0 (classic) .. 64 work items per workgroup, got %d", value);
+#ifndef NB_TUNING_SHAPES
+        NB_ASSERT(value <= 1, "the persistent-launch experiment kernels are built with make TUNING=1 only (persist = %d)", value);
+#endif
         old = s->want_persist;
         s->want_persist = value;
     } else if (!strcmp(key, "passes")) {

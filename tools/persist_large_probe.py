@@ -1,6 +1,7 @@
 import sys, time
 sys.path.insert(0, '/root/repo')
 import nbody_amd as nb
+assert nb.hip_lib().nb_hip_tuning_build(), "needs a `make -C nbody_amd/csrc TUNING=1` build (the persistent kernels are not in the shipped library)"
 import numpy as np
 n = 1 << 20
 ic = nb.make_galaxies(n, 2, seed=11037)

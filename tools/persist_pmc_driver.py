@@ -8,6 +8,8 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 import nbody_amd as nb   # noqa: E402
 
+assert nb.hip_lib().nb_hip_tuning_build(), "needs a `make -C nbody_amd/csrc TUNING=1` build (the persistent kernels are not in the shipped library)"
+
 n, persist = int(sys.argv[1]), int(sys.argv[2])
 ic = nb.make_galaxies(n, 2, seed=11037)
 w = nb.World(ic)

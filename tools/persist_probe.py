@@ -16,6 +16,8 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 import nbody_amd as nb   # noqa: E402
 
+assert nb.hip_lib().nb_hip_tuning_build(), "needs a `make -C nbody_amd/csrc TUNING=1` build (the persistent kernels are not in the shipped library)"
+
 RATE = float(os.environ.get("FLOOR_RATE", "5.54e12"))
 
 
