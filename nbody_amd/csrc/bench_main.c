@@ -47,7 +47,8 @@
  *                      hipGraph; rccl only).  Default: all the transport allows
  *   --verify K         before timing, K steps of every mode on a fresh sharded World: every rank must hold the same
  *                      bytes, and rank 0 compares them with an ordinary single-GPU World stepped the same way
- *                      (default 3; 0 = skip).  A deviation above 1e-5 relative L2 in positions fails the run.
+ *                      (default 3; with more than one rank 0 is not accepted: at least one step is always checked).  A
+ *                      deviation above 1e-5 relative L2 in positions fails the run.
  *                      Without --gpus (and with both backends): K steps of UpdateWorld_GPU against K steps of
  *                      UpdateWorld_CPU per row, relative to what the steps moved; above 1e-4 the run fails
  *   --speedup          rank 0 also times the same K steps on an ordinary single-GPU World (its own device, the other ranks
@@ -657,6 +658,11 @@ int main(int argc, char **argv) {
                 fprintf(stderr, "nbody-bench: mode graph needs --transport rccl (a host callback or barrier cannot run inside a captured graph)\n");
                 return 2;
             }
+    if (o.gpus > 1 && o.verify_steps == 0 && !o.selftest_ranks) {
+        /* a multi-rank table without its check is a table of unverified numbers: the check is not optional (one step is enough) */
+        fprintf(stderr, "nbody-bench: --verify 0 is not accepted with --gpus %d: every multi-rank row is checked (ranks agree, = one GPU); using --verify 1\n", o.gpus);
+        o.verify_steps = 1;
+    }
     /* the other ranks wait at the page while rank 0 times the single-GPU reference: K steps of the whole world on one GPU */
     if (o.speedup && o.wait_timeout_s == 180.0) o.wait_timeout_s = 3600.0;
     if (o.gpus > 1 || o.force_sharded || o.selftest_ranks) return run_ranks(&o);

@@ -1652,6 +1652,8 @@ def test_nbody_bench_c_ranks_default_shapes_and_overlap(transport):
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     head, row = [l.split() for l in r.stdout.strip().splitlines()]
     assert head[-2:] == ["us", "speedup"] and 0.05 < float(row[-1]) < 1.5 and float(row[-2]) > 10
+    # ... and a multi-rank row is never printed unchecked: --verify 0 is overridden (one step, ranks agree, = one GPU)
+    assert "--verify 0 is not accepted with --gpus 2" in r.stderr and "verify N=20000 mode=plain steps=1: ranks agree yes" in r.stderr
 
 
 def test_nbody_bench_c_one_forced_rccl_rank():
