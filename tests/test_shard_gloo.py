@@ -351,3 +351,41 @@ def test_rank_link_socket_lives_in_a_private_directory_and_refuses_strangers(tmp
     t.join(30)
     assert result["gathered"] == [b"hub", b"peer"]
     assert not os.path.exists(path)             # the name is free again once everybody is connected
+
+
+def test_bench_pure_helpers_for_the_round5_line():
+    """The arithmetic bench.py puts on the line, checked without a GPU: cycles per wave-interaction from kernel seconds and
+    the held clock, the fraction of the instruction mix's 26-cycle floor, the gather estimate with its stated parts, the
+    parsing of nb_hip_device_info, and which rank-0 output the supervisor accepts as a complete headline."""
+    import json
+    root = os.path.dirname(HERE)
+    sys.path.insert(0, root)
+    import bench
+    info = "AMD Instinct MI355X gfx950:sramecc+:xnack- 256 2400 pci=0000:f1:00"
+    assert bench.device_cus(info) == 256 and bench.device_cus("AMD-GPU gfx950 304 2100") == 304 and bench.device_cus("?") == 256
+    # one launch of the headline: 2.7465e11 interactions in 47.88 ms at 2.354 GHz on 1024 SIMDs -> 26.9 cycles
+    sampled = {"clock_ghz": 2.35, "per_xcd_ghz": [2.373, 2.340, 2.371, 2.338, 2.377, 2.331, 2.378, 2.322]}
+    f = bench.held_clock_fields({"clock_ghz": 2.27}, sampled, 47.88e-3, 2.7465e11, info, 80.3)
+    assert abs(f["held_clock_ghz"] - 2.35375) < 1e-9 and abs(f["held_clock_ghz_slowest_xcd"] - 2.322) < 1e-12
+    assert abs(f["cycles_per_wave_interaction"] - 26.89) < 0.02 and abs(f["frac_of_mix_ceiling"] - 26.0 / f["cycles_per_wave_interaction"]) < 1e-12
+    assert abs(f["cycles_per_wave_interaction_slowest_xcd"] - 26.53) < 0.02
+    assert abs(f["mix_ceiling_frac_at_nominal_clock"] - 14.0 / 26.0) < 1e-12 and abs(f["frac_at_held_clock"] - 80.3 / (157.3 * 2.35375 / 2.4)) < 1e-12
+    # the probe alone (no sampler leg): its clock is used, and labelled as reading low
+    g = bench.held_clock_fields({"clock_ghz": 2.27}, None, 47.88e-3, 2.7465e11, info, 80.3)
+    assert g["held_clock_ghz"] == 2.27 and "LOW" in g["held_clock_source"]
+    assert bench.held_clock_fields(None, None, 47.88e-3, 2.7465e11, info, 80.3)["held_clock_ghz"] is None
+    # gather estimate: the slice over its own link + the assumed fixed latency, nothing for one rank
+    assert bench.gather_estimate_ms(65536, 1) == 0.0
+    est = bench.gather_estimate_ms(65536, 8)
+    assert abs(est - (65536 * 8 / 153e9 * 1e3 + bench.GATHER_LATENCY_ASSUMED_MS)) < 1e-12 and 0.05 < est < 0.06
+    # what counts as a headline: metric + value, and for real multi-rank runs a self-check that passed
+    ok = json.dumps({"metric": "m", "value": 1.0, "self_check": {"ranks_agree": True, "ok": True}})
+    assert bench._headline_of(["noise\n", ok + "\n"], 8, False)[1] is None
+    assert bench._headline_of([ok], 1, False)[1] is None
+    assert "no self_check" in bench._headline_of([json.dumps({"metric": "m", "value": 1.0})], 2, False)[1]
+    assert bench._headline_of([json.dumps({"metric": "m", "value": 1.0})], 2, True)[1] is None           # dry run
+    bad = json.dumps({"metric": "m", "value": 1.0, "self_check": {"ranks_agree": False}})
+    assert bench._headline_of([bad], 2, False)[1].startswith("self_check failed")
+    assert bench._headline_of(["not json\n"], 2, False) == (None, "rank 0 wrote no JSON line")
+    share = bench.host_cpu_share()
+    assert share["threads"] >= 1 and share["threads_from"] and share["os_cpu_count"] >= 1
