@@ -570,6 +570,9 @@ def parse_args(argv=None):
     ap.add_argument("--rehearse-rccl-failure", action="store_true",
                     help="rehearsal only: in an rccl attempt the last rank leaves with exit code 3 right after the rendezvous, like the "
                          "library's watchdog does when ncclCommInitRank never completes -- exercises --transport auto's fallback")
+    ap.add_argument("--rehearse-hang", action="store_true",
+                    help="rehearsal only: every rank sleeps for a minute right after the rendezvous (a collective that never "
+                         "completes), to exercise the supervisor's clean-up when it is told to stop")
     ap.add_argument("--attempt-timeout-s", type=float, default=900.0,
                     help="N > 1: the supervisor ends (by exact pid) rank processes of an attempt that runs longer than this")
     return ap.parse_args(argv)
@@ -623,6 +626,10 @@ def worker_main(args):
 
             link = RankLink(rank, world, name="nbody_bench_%s_%s_a%d" % (os.environ["MASTER_PORT"],
                                                                         os.environ.get("TORCHELASTIC_RUN_ID", "none"), attempt))
+            if args.rehearse_hang:
+                link.barrier()
+                time.sleep(60.0)
+                os._exit(9)
             if args.rehearse_rccl_failure and args.transport == "rccl" and world > 1:
                 link.barrier()
                 if rank == world - 1:
@@ -1429,6 +1436,26 @@ def supervise(args, argv):
             passthrough.append(a)
     transports = ["rccl", "direct"] if args.transport == "auto" else [args.transport]
     attempts, line, why = [], None, "no attempt ran"
+    ranks = []
+
+    def end_my_ranks(*_):
+        """Whatever ends this supervisor early -- a launcher's SIGTERM, an exception on the supervisors' link -- must not
+        leave rank processes behind on the GPUs: end exactly the children this process started."""
+        for p in ranks:
+            p.end()
+
+    import signal
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, lambda n, f: (end_my_ranks(), os._exit(128 + n)))
+    try:
+        return _supervise_attempts(args, transports, passthrough, local, world, my_rank, port, run_id, sup, everyone, mode, ranks,
+                                   attempts, line, why)
+    finally:
+        end_my_ranks()
+
+
+def _supervise_attempts(args, transports, passthrough, local, world, my_rank, port, run_id, sup, everyone, mode, ranks, attempts, line, why):
+    verdict = 0
     for attempt, transport in enumerate(transports):
         env = dict(os.environ, NB_BENCH_WORKER="1", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    NB_BENCH_ATTEMPT=str(attempt), TORCHELASTIC_RUN_ID=run_id)
@@ -1436,8 +1463,8 @@ def supervise(args, argv):
         if len(transports) > 1 and attempt == 0:
             env.setdefault("NB_HIP_COMM_TIMEOUT_S", "75")   # there is a fallback: do not sit out the library's 180 s
         t0 = time.monotonic()
-        ranks = [RankProcess(passthrough + ["--transport", transport], dict(env, RANK=str(r), LOCAL_RANK=str(lr)), r, r == 0)
-                 for r, lr in local]
+        ranks[:] = [RankProcess(passthrough + ["--transport", transport], dict(env, RANK=str(r), LOCAL_RANK=str(lr)), r, r == 0)
+                    for r, lr in local]
         first_failure = None
         while True:
             mine = [p.status() for p in ranks]

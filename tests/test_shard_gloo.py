@@ -389,3 +389,27 @@ def test_bench_pure_helpers_for_the_round5_line():
     assert bench._headline_of(["not json\n"], 2, False) == (None, "rank 0 wrote no JSON line")
     share = bench.host_cpu_share()
     assert share["threads"] >= 1 and share["threads_from"] and share["os_cpu_count"] >= 1
+
+
+def test_bench_supervisor_takes_its_ranks_with_it_when_told_to_stop():
+    """A supervisor that is ended from outside (a launcher's SIGTERM when another rank failed, Ctrl-C) must not leave rank
+    processes behind on the GPUs: it ends exactly the children it started, then leaves."""
+    import signal
+    import time
+    import psutil
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    sup = subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--particles", "65536", "--dry-run",
+                            "--rehearse-hang"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root)
+    kids = []
+    for _ in range(200):
+        kids = psutil.Process(sup.pid).children(recursive=True)
+        if len(kids) == 3:
+            break
+        time.sleep(0.05)
+    assert len(kids) == 3, kids
+    time.sleep(1.0)
+    sup.send_signal(signal.SIGTERM)
+    assert sup.wait(timeout=30) == 128 + signal.SIGTERM
+    gone, alive = psutil.wait_procs(kids, timeout=10)
+    assert not alive, alive
