@@ -1318,6 +1318,15 @@ def _extra_entry(n, m, overlap, sharded_graph, steps, elapsed, detail, world):
 RUNNING = -1000   # status of a rank process that has not ended yet (exit codes and -signal numbers are > -1000)
 
 
+def _die_with_parent():
+    """In the child, between fork and exec: a rank never outlives the supervisor that started it, however that one ends
+    (PR_SET_PDEATHSIG survives the exec; the signal handlers of supervise() cover the polite ways of being stopped)."""
+    try:
+        C.CDLL(None).prctl(1, 9)   # PR_SET_PDEATHSIG, SIGKILL
+    except Exception:
+        pass
+
+
 class RankProcess:
     """One worker (this file, NB_BENCH_WORKER=1) for one rank of one attempt, started by a process that never touches the
     GPU.  Rank 0's stdout (the JSON line) is captured; every worker's stderr is forwarded as it comes and its tail kept."""
@@ -1325,7 +1334,7 @@ class RankProcess:
     def __init__(self, argv, env, rank, capture_stdout):
         self.rank = rank
         self.lines, self.tail = [], []
-        self.proc = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+        self.proc = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, preexec_fn=_die_with_parent,
                                      stdout=subprocess.PIPE if capture_stdout else sys.stderr.fileno(), stderr=subprocess.PIPE)
         self.threads = [threading.Thread(target=self._pump_err, daemon=True)]
         if capture_stdout:

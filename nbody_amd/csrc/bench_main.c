@@ -68,6 +68,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/prctl.h>
 #include <sys/types.h>
 #include <sys/wait.h>
 #include <time.h>
@@ -478,6 +479,7 @@ static int run_ranks_once(const Options *o) {
     fflush(stdout);
     fflush(stderr);
     pid_t pids[NB_RANKS_MAX];
+    const pid_t parent = getpid();
     for (int r = 0; r < P; r++) {
         pids[r] = fork();
         if (pids[r] < 0) {
@@ -487,6 +489,9 @@ static int run_ranks_once(const Options *o) {
             return 2;
         }
         if (pids[r] == 0) {
+            /* a rank never outlives the parent that started it (a parent ended from outside must not leave ranks on the GPUs) */
+            prctl(PR_SET_PDEATHSIG, SIGKILL);
+            if (getppid() != parent) _exit(4);
             nb_rank_page_attach(pg, r);
             const int rc = o->selftest_ranks ? selftest_rank(o, pg) : run_rank(o, pg);
             fflush(stdout);

@@ -413,3 +413,16 @@ def test_bench_supervisor_takes_its_ranks_with_it_when_told_to_stop():
     assert sup.wait(timeout=30) == 128 + signal.SIGTERM
     gone, alive = psutil.wait_procs(kids, timeout=10)
     assert not alive, alive
+    # ... and not even a SIGKILL of the supervisor leaves them behind (PR_SET_PDEATHSIG in every rank process)
+    sup = subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--particles", "65536", "--dry-run",
+                            "--rehearse-hang"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root)
+    for _ in range(200):
+        kids = psutil.Process(sup.pid).children(recursive=True)
+        if len(kids) == 2:
+            break
+        time.sleep(0.05)
+    assert len(kids) == 2, kids
+    sup.kill()
+    sup.wait(timeout=30)
+    gone, alive = psutil.wait_procs(kids, timeout=10)
+    assert not alive, alive
