@@ -1399,7 +1399,7 @@ def _headline_of(lines, world, dry_run):
     return None, "rank 0 wrote no JSON line"
 
 
-def supervise(args, argv):
+class Supervisor:
     """`bench.py --gpus N` (N > 1) started bare, or started once per rank by torch.distributed.run: THIS process never makes
     a GPU call.  Bare: it starts N fresh rank processes itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT in their
     environment) -- the shape of the reference harness, one plain command (src/bench.c:41-74).  Under torch.distributed.run:
@@ -1407,77 +1407,69 @@ def supervise(args, argv):
     Either way an attempt whose ranks do not all deliver -- RCCL that does not come up (the library's watchdog leaves with 3,
     its error convention with abort()), a self-check that fails -- is followed, with --transport auto, by a SECOND attempt in
     fresh processes over the direct exchange; the line then carries "transport_fallback".  Nothing is ever retried or
-    re-executed inside a process that has touched the GPU; stragglers are ended by exact pid.
+    re-executed inside a process that has touched the GPU; stragglers are ended by exact pid, and no rank outlives the
+    supervisor that started it.
     Exit code: what the ranks of the LAST attempt left with -- 0 only when every one of them did; a run whose optional leg
     stalled (4) or aborted (6) after the headline still writes the complete line ("extras_aborted",
     launch.attempts[].child_rcs) and still does not report success."""
-    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ
-    if under_launcher:
-        my_rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-        local = [(my_rank, int(os.environ.get("LOCAL_RANK", my_rank)))]
-        port = os.environ["MASTER_PORT"]
-        mode = "torch.distributed.run: every rank process stays GPU-free and supervises one fresh worker"
-    else:
-        my_rank, world = 0, args.gpus
-        local = [(r, r) for r in range(world)]
-        port = str(_free_port())
-        mode = f"bare: bench.py started its {world} rank processes itself"
-    run_id = os.environ.get("TORCHELASTIC_RUN_ID", "none")
-    sup = None
-    if under_launcher and world > 1:
-        from nbody_amd.ranklink import RankLink
-        sup = RankLink(my_rank, world, name=f"nbody_sup_{port}_{run_id}")
 
-    def everyone(values):
+    GRACE_S = 20.0   # what the other ranks get once one has left with an error (rank 0 may be writing its line)
+
+    def __init__(self, args, argv):
+        self.args = args
+        under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ
+        if under_launcher:
+            self.rank, self.world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+            self.local = [(self.rank, int(os.environ.get("LOCAL_RANK", self.rank)))]
+            self.port = os.environ["MASTER_PORT"]
+            self.mode = "torch.distributed.run: every rank process stays GPU-free and supervises one fresh worker"
+        else:
+            self.rank, self.world = 0, args.gpus
+            self.local = [(r, r) for r in range(self.world)]
+            self.port = str(_free_port())
+            self.mode = f"bare: bench.py started its {self.world} rank processes itself"
+        self.run_id = os.environ.get("TORCHELASTIC_RUN_ID", "none")
+        self.link = None
+        if under_launcher and self.world > 1:
+            from nbody_amd.ranklink import RankLink
+            self.link = RankLink(self.rank, self.world, name=f"nbody_sup_{self.port}_{self.run_id}")
+        # what the workers get: the same command line minus what the supervisor decides
+        self.passthrough, skip = [], False
+        for a in argv:
+            if skip:
+                skip = False
+            elif a == "--transport":
+                skip = True
+            elif not a.startswith("--transport="):
+                self.passthrough.append(a)
+        self.transports = ["rccl", "direct"] if args.transport == "auto" else [args.transport]
+        self.ranks, self.attempts = [], []
+
+    def everyone(self, values):
         """Status of every rank, indexed by rank (bare: they are all mine)."""
-        if sup is None:
+        if self.link is None:
             return list(values)
-        return [v for row in sup.allgather([float(v) for v in values]) for v in (int(x) for x in row)]
+        return [int(x) for row in self.link.allgather([float(v) for v in values]) for x in row]
 
-    # what the workers get: the same command line minus what the supervisor decides
-    passthrough, skip = [], False
-    for a in argv:
-        if skip:
-            skip = False
-        elif a == "--transport":
-            skip = True
-        elif not a.startswith("--transport="):
-            passthrough.append(a)
-    transports = ["rccl", "direct"] if args.transport == "auto" else [args.transport]
-    attempts, line, why = [], None, "no attempt ran"
-    ranks = []
-
-    def end_my_ranks(*_):
+    def end_my_ranks(self):
         """Whatever ends this supervisor early -- a launcher's SIGTERM, an exception on the supervisors' link -- must not
         leave rank processes behind on the GPUs: end exactly the children this process started."""
-        for p in ranks:
+        for p in self.ranks:
             p.end()
 
-    import signal
-    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
-        signal.signal(sig, lambda n, f: (end_my_ranks(), os._exit(128 + n)))
-    try:
-        return _supervise_attempts(args, transports, passthrough, local, world, my_rank, port, run_id, sup, everyone, mode, ranks,
-                                   attempts, line, why)
-    finally:
-        end_my_ranks()
-
-
-def _supervise_attempts(args, transports, passthrough, local, world, my_rank, port, run_id, sup, everyone, mode, ranks, attempts, line, why):
-    verdict = 0
-    for attempt, transport in enumerate(transports):
-        env = dict(os.environ, NB_BENCH_WORKER="1", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   NB_BENCH_ATTEMPT=str(attempt), TORCHELASTIC_RUN_ID=run_id)
+    def attempt(self, index, transport):
+        """One set of fresh rank processes over `transport`: (line or None, why it does not count or None, record)."""
+        env = dict(os.environ, NB_BENCH_WORKER="1", WORLD_SIZE=str(self.world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(self.port),
+                   NB_BENCH_ATTEMPT=str(index), TORCHELASTIC_RUN_ID=self.run_id)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if len(transports) > 1 and attempt == 0:
+        if len(self.transports) > 1 and index == 0:
             env.setdefault("NB_HIP_COMM_TIMEOUT_S", "75")   # there is a fallback: do not sit out the library's 180 s
         t0 = time.monotonic()
-        ranks[:] = [RankProcess(passthrough + ["--transport", transport], dict(env, RANK=str(r), LOCAL_RANK=str(lr)), r, r == 0)
-                    for r, lr in local]
+        self.ranks[:] = [RankProcess(self.passthrough + ["--transport", transport], dict(env, RANK=str(r), LOCAL_RANK=str(lr)), r, r == 0)
+                         for r, lr in self.local]
         first_failure = None
         while True:
-            mine = [p.status() for p in ranks]
-            seen = everyone(mine)
+            seen = self.everyone([p.status() for p in self.ranks])
             if all(v != RUNNING for v in seen):
                 break
             now = time.monotonic()
@@ -1485,54 +1477,70 @@ def _supervise_attempts(args, transports, passthrough, local, world, my_rank, po
                 first_failure = now
             # a rank that left with an error takes the attempt with it: the others get a moment (rank 0 may be writing
             # its line; the library's own watchdogs may still fire), then go -- by exact pid
-            if (first_failure is not None and now - first_failure > 20.0) or now - t0 > args.attempt_timeout_s:
-                for p in ranks:
-                    p.end()
+            if (first_failure is not None and now - first_failure > self.GRACE_S) or now - t0 > self.args.attempt_timeout_s:
+                self.end_my_ranks()
             time.sleep(0.25)
-        for p in ranks:
+        for p in self.ranks:
             p.finish()
-        rcs = everyone([p.status() for p in ranks])
+        rcs = self.everyone([p.status() for p in self.ranks])
         record = {"transport": transport, "child_rcs": rcs, "seconds": round(time.monotonic() - t0, 2)}
         # every rank's last words, indexed by rank (under a launcher each supervisor holds one worker's)
-        tails = ["".join(p.tail)[-900:] for p in ranks]
-        if sup is not None:
-            tails = [t.decode(errors="replace") for t in sup.allgather(tails[0].encode())]
-        verdict = 0
-        if my_rank == 0:
-            line, why = _headline_of(ranks[0].lines, world, args.dry_run)
-            verdict = 1 if (line is not None and why is None) else 0
-            if not verdict:
+        tails = ["".join(p.tail)[-900:] for p in self.ranks]
+        if self.link is not None:
+            tails = [t.decode(errors="replace") for t in self.link.allgather(tails[0].encode())]
+        line, why = None, None
+        if self.rank == 0:
+            line, why = _headline_of(self.ranks[0].lines, self.world, self.args.dry_run)
+            if line is None or why is not None:
                 # whose stderr explains it: a rank that left with something other than Python's generic 1, if there is one
-                bad = sorted(range(world), key=lambda r: (rcs[r] == 0, rcs[r] == 1))[0]
+                bad = sorted(range(self.world), key=lambda r: (rcs[r] == 0, rcs[r] == 1))[0]
                 record["why_not"] = why
                 record["stderr_tail"] = f"[rank {bad}, rc {rcs[bad]}] " + tails[bad]
-        if sup is not None:
-            verdict = int(sup.broadcast(verdict if my_rank == 0 else None, src=0))
-        attempts.append(record)
-        if verdict:
-            break
-    if sup is not None:
-        sup.barrier()
-        sup.close()
-    last = [rc for rc in attempts[-1]["child_rcs"] if rc not in (0, RUNNING)]
-    code = (min(abs(last[0]), 255) or 1) if last else 0      # the worst the final attempt's ranks left with; 0 only when all did
-    if my_rank != 0:
-        return code if verdict else (code or 1)
-    launch = {"mode": mode, "attempts": attempts}
-    if verdict:
-        line["launch"] = launch
-        if len(attempts) > 1:
-            first = attempts[0]
-            line["transport_fallback"] = {"from": first["transport"], "to": attempts[-1]["transport"], "rc": first["child_rcs"],
-                                          "why": first.get("why_not"), "stderr_tail": first.get("stderr_tail", "")[-600:]}
-        print(json.dumps(line), flush=True)
-        return code
-    # no complete headline from any attempt: still one line, saying so
-    partial = line if isinstance(line, dict) else {}
-    partial.update({"metric": partial.get("metric", "particle-pair interactions/sec at N=2^20"), "value": partial.get("value"),
-                    "unit": "interactions/s", "n_gpus": world, "error": why, "launch": launch})
-    print(json.dumps(partial), flush=True)
-    return code or 1
+        good = 1 if (line is not None and why is None) else 0
+        if self.link is not None:
+            good = int(self.link.broadcast(good if self.rank == 0 else None, src=0))
+        self.attempts.append(record)
+        return line, why, bool(good)
+
+    def run(self):
+        line, why, good = None, "no attempt ran", False
+        for index, transport in enumerate(self.transports):
+            line, why, good = self.attempt(index, transport)
+            if good:
+                break
+        if self.link is not None:
+            self.link.barrier()
+            self.link.close()
+        last = [rc for rc in self.attempts[-1]["child_rcs"] if rc not in (0, RUNNING)]
+        code = (min(abs(last[0]), 255) or 1) if last else 0      # the worst the final attempt's ranks left with; 0 only when all did
+        if self.rank != 0:
+            return code if good else (code or 1)
+        launch = {"mode": self.mode, "attempts": self.attempts}
+        if good:
+            line["launch"] = launch
+            if len(self.attempts) > 1:
+                first = self.attempts[0]
+                line["transport_fallback"] = {"from": first["transport"], "to": self.attempts[-1]["transport"], "rc": first["child_rcs"],
+                                              "why": first.get("why_not"), "stderr_tail": first.get("stderr_tail", "")[-600:]}
+            print(json.dumps(line), flush=True)
+            return code
+        # no complete headline from any attempt: still one line, saying so
+        partial = line if isinstance(line, dict) else {}
+        partial.update({"metric": partial.get("metric", "particle-pair interactions/sec at N=2^20"), "value": partial.get("value"),
+                        "unit": "interactions/s", "n_gpus": self.world, "error": why, "launch": launch})
+        print(json.dumps(partial), flush=True)
+        return code or 1
+
+
+def supervise(args, argv):
+    import signal
+    sup = Supervisor(args, argv)
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, lambda n, f: (sup.end_my_ranks(), os._exit(128 + n)))
+    try:
+        return sup.run()
+    finally:
+        sup.end_my_ranks()
 
 
 def main(argv=None):
