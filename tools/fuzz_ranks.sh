@@ -1,8 +1,8 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): the C harness' multi-process paths over ragged sizes, rank counts and transports.
-# One wave per workgroup (NB_HIP_W=1 NB_HIP_K=1) makes the in-stream step independent of the launch geometry, so every
+# One wave per workgroup (--one-wave; the NB_HIP_W / NB_HIP_K presets exist in TUNING=1 builds only since ABI 0.3.0) makes the in-stream step independent of the launch geometry, so every
 # "plain" verification must be bit-equal to the single-GPU World; "overlap" rows must stay within the harness' 1e-5.
-# usage: tools/fuzz_ranks.sh > gpurun_out/r04_fuzz_ranks.txt
+# usage: tools/fuzz_ranks.sh > gpurun_out/r05_fuzz_ranks.txt
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 B=$R/nbody_amd/lib/nbody-bench
@@ -11,7 +11,7 @@ for T in shm ipc; do
   for P in 2 3 4; do
     for N in 200 333 777 1000 2111 4097 10000 30011; do
       runs=$((runs + 1))
-      out=$(NB_HIP_W=1 NB_HIP_K=1 timeout -k 10 120 $B --gpus $P --transport $T --n $N --steps 7 --warmup 2 --dt 0.01 --modes plain,overlap --verify 5 --own-rng --seed $((N + P)) 2>&1)
+      out=$(timeout -k 10 120 $B --gpus $P --transport $T --one-wave --n $N --steps 7 --warmup 2 --dt 0.01 --modes plain,overlap --verify 5 --own-rng --seed $((N + P)) 2>&1)
       rc=$?
       plain=$(echo "$out" | grep "mode=plain" | grep -c "ranks agree yes.*bitwise yes")
       over=$(echo "$out" | grep "mode=overlap" | grep -c "ranks agree yes")

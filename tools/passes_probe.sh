@@ -1,5 +1,5 @@
 #!/bin/bash
-# FETCH_SIZE and step time of bench.py for several source-pass counts (NB_HIP_PASSES); run on the GPU box.
+# FETCH_SIZE and step time of bench.py for several source-pass counts (NB_HIP_PASSES: needs a `make TUNING=1` build since ABI 0.3.0); run on the GPU box.
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/passes; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
