@@ -1969,3 +1969,33 @@ def test_single_gpu_bench_line_survives_a_leg_that_aborts(leg):
     out = json.loads(lines[0])
     assert out["extras_aborted"] == f"{leg} (fatal signal)" and out["value"] > 1e12 and out["roofline"]["frac"] > 0.3
     assert ("parity" in out) == (leg != "clock probe")      # legs that finished before the abort are on the line
+
+
+@pytest.mark.parametrize("ranks", [2, 3, 8])
+def test_bench_shard_leg_times_every_ranks_step_and_stamps_it(ranks):
+    """bench.py's S-legs (extra_configs S2 / S4 / S8 / C5S8) at a small size: all shards of one world in this process, every
+    member's kernels under their own HIP event pairs (nb_hip_local_group_step with the timing knob), so the entry says what
+    ONE rank's step costs for every rank, with a parity stamp against float64 and the stated gather estimate."""
+    sys.path.insert(0, nb.ROOT)
+    import bench
+    n = 65536
+    _, part, m = bench_universe(n)
+    one = nb.SimPipeline(n, m)
+    one.configure(graph=0)
+    one.set_data(part)
+    one.update(2, 0.01)
+    t0 = time.perf_counter()
+    one.update(5, 0.01)
+    t1_ms = (time.perf_counter() - t0) / 5 * 1e3
+    one.close()
+    e = bench.shard_leg(nb, f"S{ranks}", part, m, ranks, 3, t1_ms=t1_ms)
+    k = e["shard_kernel_ms_per_step"]
+    assert e["ranks"] == ranks and 0 < k["min"] <= k["mean"] <= k["max"] < t1_ms        # a shard's step is shorter than the whole step
+    assert k["max"] >= 0.5 * t1_ms / ranks                                               # ... and not shorter than its share allows
+    assert 0.4 <= e["compute_scaling_efficiency"] <= 1.2, e
+    assert e["all_shards_wall_ms_per_step"] >= ranks * k["min"] * 0.9
+    p = e["parity"]
+    assert p["worst_ratio"] <= 1.0 and p["integrator_bit_exact"] and p["static_fields_equal"], p
+    plan = nb.shard_plan(n, m, 0, ranks)
+    assert abs(e["gather_estimate_ms"] - bench.gather_estimate_ms(plan["mass_chunk"], ranks)) < 1e-12 and "NOT measured" in e["gather_estimate_source"]
+    assert abs(e["predicted_steps_per_sec"] - 1e3 / (k["max"] + e["gather_estimate_ms"])) < 1e-6
