@@ -187,48 +187,46 @@ def test_frame_loop_read_back_modes_give_the_same_frames(golden, readback):
     """The GUI's pattern (reference src/main.c:157-163,237): UpdateWorld_GPU then GetWorldParticles every frame.  With
     readback = 1 / 2 (auto) the merge kernel rides in the update's submission and stores straight into the World's
     page-locked array; every frame must equal the lazy path's, also when the pattern breaks (two updates in a row,
-    a CPU step in between, a Get into a foreign buffer through the seam)."""
+    a CPU step in between, a Get into a foreign buffer through the seam).  The mode is set through the tuning hook on the
+    World's own pipeline (the library that ships reads no NB_HIP_READBACK), and read back: a knob that is silently ignored
+    fails here instead of comparing the default with itself."""
     ic = golden("ic_1024.bin")
-    env_old = os.environ.get("NB_HIP_READBACK")
     frames = {}
     for mode in (0, readback):
-        os.environ["NB_HIP_READBACK"] = str(mode)
-        try:
-            w = nb.World(ic)
-            out = []
-            for f in range(5):
-                w.update_gpu(0.01, 1 + (f & 1))
-                out.append(w.particles())
-            w.update_gpu(0.01, 1)
-            w.update_gpu(0.01, 2)          # update after update: the streak ends, next Get is lazy again
+        w = nb.World(ic)
+        assert w.tune(readback=mode) == {"readback": 2}      # the shipped default is auto
+        assert w.tune(readback=mode) == {"readback": mode}    # ... and the hook took
+        out = []
+        for f in range(5):
+            w.update_gpu(0.01, 1 + (f & 1))
             out.append(w.particles())
-            w.update_cpu(0.01, 1)          # pulls (nothing stale), steps on the CPU, marks the host newer
-            w.update_gpu(0.01, 1)          # re-upload, step
+        w.update_gpu(0.01, 1)
+        w.update_gpu(0.01, 2)          # update after update: the streak ends, next Get is lazy again
+        out.append(w.particles())
+        w.update_cpu(0.01, 1)          # pulls (nothing stale), steps on the CPU, marks the host newer
+        w.update_gpu(0.01, 1)          # re-upload, step
+        out.append(w.particles())
+        for f in range(3):
+            w.update_gpu(0.005, 3)
             out.append(w.particles())
-            for f in range(3):
-                w.update_gpu(0.005, 3)
-                out.append(w.particles())
-            w.close()
-        finally:
-            if env_old is None:
-                os.environ.pop("NB_HIP_READBACK", None)
-            else:
-                os.environ["NB_HIP_READBACK"] = env_old
+        assert w.tune(readback=2) == {"readback": mode}       # nothing reset it on the way
+        w.close()
         frames[mode] = out
     for a, b in zip(frames[0], frames[readback]):
         assert a.tobytes() == b.tobytes()
 
 
 @pytest.mark.parametrize("n", [1024, 4096])
-def test_zero_copy_upload_equals_the_dma_upload(golden, n, monkeypatch):
+def test_zero_copy_upload_equals_the_dma_upload(golden, n):
     """SetSimulationData from the World's page-locked array: the split kernel reads the records over PCIe itself
-    (default) or after a DMA copy into device staging (NB_HIP_ZERO_COPY_UPLOAD=0) -- same bytes either way, also
+    (default) or after a DMA copy into device staging (tuning hook zero_copy_upload = 0) -- same bytes either way, also
     when the CPU stepper dirtied the array in between (reference world.c:76-81,99-118 protocol)."""
     ic = golden(f"ic_{n}.bin")
     outs = []
-    for mode in ("1", "0"):
-        monkeypatch.setenv("NB_HIP_ZERO_COPY_UPLOAD", mode)
+    for mode in (1, 0):
         w = nb.World(ic)
+        assert w.tune(zero_copy_upload=mode) == {"zero_copy_upload": 1}     # default: zero-copy
+        assert w.tune(zero_copy_upload=mode) == {"zero_copy_upload": mode}
         w.update_gpu(0.01, 2)
         w.update_cpu(0.01, 1)
         w.update_gpu(0.01, 1)       # re-upload of the CPU-stepped array
