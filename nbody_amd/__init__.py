@@ -401,11 +401,61 @@ class World:
             return np.empty((0, 8), dtype=np.float32)
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n.value, 8)).copy()
 
+    def pipeline(self):
+        """GetWorldPipeline: the SimPipeline handle behind this World (for nb_hip_configure / the tuning hooks)."""
+        return nbody_lib().GetWorldPipeline(self._h)
+
+    def tune(self, **knobs):
+        """Set knobs on the World's pipeline (nb_hip_configure for the public five, nb_hip_tune for the hooks); returns the
+        previous value of each, so that a caller can see that a knob took."""
+        old = {}
+        for k, v in knobs.items():
+            fn = hip_lib().nb_hip_configure if k in PUBLIC_KNOBS else hip_lib().nb_hip_tune
+            old[k] = int(fn(self.pipeline(), k.encode(), int(v)))
+        return old
+
     def update_cpu(self, dt, n):
         nbody_lib().UpdateWorld_CPU(self._h, dt, n)
 
     def update_gpu(self, dt, n):
         nbody_lib().UpdateWorld_GPU(self._h, dt, n)
+
+
+_cpu_best = None
+
+
+def cpu_best_lib():
+    """libnbody_cpu_best.so (csrc/cpu_best.c): the informational CPU variants of sim_cpu.c; never behind UpdateWorld_CPU."""
+    global _cpu_best
+    if _cpu_best is None:
+        path = os.path.join(LIB_DIR, "libnbody_cpu_best.so")
+        _build_if_missing(path)
+        lib = C.CDLL(path)
+        lib.nb_cpu_variant_count.restype = C.c_int
+        lib.nb_cpu_variant_name.restype = C.c_char_p
+        lib.nb_cpu_variant_name.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
+        lib.nb_cpu_variant_update.restype = C.c_int
+        lib.nb_cpu_variant_update.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32]
+        _cpu_best = lib
+    return _cpu_best
+
+
+def cpu_variants():
+    """[(isa, runs on this CPU, description)] of the informational CPU steppers."""
+    lib, out = cpu_best_lib(), []
+    for i in range(lib.nb_cpu_variant_count()):
+        ok, what = C.c_int(0), C.c_char_p()
+        name = lib.nb_cpu_variant_name(i, C.byref(ok), C.byref(what))
+        out.append((name.decode(), bool(ok.value), what.value.decode()))
+    return out
+
+
+def cpu_variant_update(isa, particles, mass_len, dt, n=1):
+    """n Jacobi steps of a PARTITIONED array (sources first) with one informational CPU variant; returns the new array."""
+    a = as_particles(particles).copy()
+    if cpu_best_lib().nb_cpu_variant_update(isa.encode(), a.ctypes.data, a.shape[0], mass_len, dt, n) != 0:
+        raise RuntimeError(f"CPU variant {isa!r} is unknown or not supported by this CPU")
+    return a
 
 
 def make_galaxies(particle_count, galaxy_count, seed=None, own_rng=False):

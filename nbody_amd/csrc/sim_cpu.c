@@ -20,8 +20,22 @@
  * and the sum in float64 from the same fp32 inputs, sources in index order, the sum rounded once to the fp32 acc; the
  * integrator stays the reference's fp32 mul-then-add.  It is the tie-breaker the fp32 tolerance is stated against.
  *
+ * Informational variants (SURVEY.md section 8d "best CPU" row; NOT bit-exact with any reference build, never behind
+ * UpdateWorld_CPU): -DNB_SIMD_AVX2FMA (8 lanes, built -mavx2 -mfma with contraction allowed: what -march=native makes
+ * of the reference's AVX source), -DNB_SIMD_AVX512 (16 lanes, -mavx512f -mfma), and with -DNB_CPU_RSQRT on top of either
+ * the sqrt + div pair replaced by the hardware reciprocal-sqrt estimate plus one Newton step (what a CPU-tuned build
+ * would do).  They are compiled with -DNB_CPU_SUFFIX=<name>, which renames the three entry points, into
+ * libnbody_cpu_best.so (cpu_best.c picks by __builtin_cpu_supports); bench.py times them beside the -mavx reference row.
+ *
  * Build: -mavx -ffp-contract=off (no FMA contraction), see csrc/Makefile.
  */
+#ifdef NB_CPU_SUFFIX
+#define NB_CPU_CAT2(a, b) a##_##b
+#define NB_CPU_CAT(a, b) NB_CPU_CAT2(a, b)
+#define CpuSimCreate NB_CPU_CAT(CpuSimCreate, NB_CPU_SUFFIX)
+#define CpuSimDestroy NB_CPU_CAT(CpuSimDestroy, NB_CPU_SUFFIX)
+#define CpuSimStep NB_CPU_CAT(CpuSimStep, NB_CPU_SUFFIX)
+#endif
 #include "sim_cpu.h"
 #include "nb_util.h"
 
@@ -64,7 +78,21 @@ typedef float vf;
 #define vf_mul(a, b) ((a) * (b))
 #define vf_div(a, b) ((a) / (b))
 #define vf_sqrt(a) sqrtf(a)
-#else /* AVX: the reference's default build and the parity target */
+#elif defined(NB_SIMD_AVX512)
+#include <immintrin.h>
+#define V 16u
+typedef __m512 vf;
+#define vf_set1 _mm512_set1_ps
+#define vf_zero _mm512_setzero_ps
+#define vf_load _mm512_load_ps
+#define vf_storeu _mm512_storeu_ps
+#define vf_add _mm512_add_ps
+#define vf_sub _mm512_sub_ps
+#define vf_mul _mm512_mul_ps
+#define vf_div _mm512_div_ps
+#define vf_sqrt _mm512_sqrt_ps
+#define vf_rsqrt _mm512_rsqrt14_ps /* relative error <= 2^-14; one Newton step brings it to ~6e-9 */
+#else /* AVX (8 lanes): the reference's default build and the parity target; NB_SIMD_AVX2FMA = the same source, other flags */
 #include <immintrin.h>
 #define V 8u
 typedef __m256 vf;
@@ -77,10 +105,11 @@ typedef __m256 vf;
 #define vf_mul _mm256_mul_ps
 #define vf_div _mm256_div_ps
 #define vf_sqrt _mm256_sqrt_ps
+#define vf_rsqrt _mm256_rsqrt_ps /* relative error <= 1.5 * 2^-12; one Newton step brings it to ~2e-7 */
 #endif
 
 struct CpuSim {
-    float *sx, *sy, *sm; /* snapshot, 32-byte aligned, zero-padded to a multiple of V */
+    float *sx, *sy, *sm; /* snapshot, 64-byte aligned, zero-padded to a multiple of V */
     uint32_t capacity;   /* padded element count */
 };
 
@@ -88,10 +117,10 @@ CpuSim *CpuSimCreate(uint32_t mass_len) {
     CpuSim *sim = NB_NEW(1, CpuSim);
     NB_CHECK(sim != NULL, "Failed to alloc CpuSim");
     sim->capacity = (mass_len + V - 1u) / V * V;
-    size_t bytes = ((size_t)(sim->capacity ? sim->capacity : V) * sizeof(float) + 31u) / 32u * 32u;
-    sim->sx = (float *)aligned_alloc(32, bytes);
-    sim->sy = (float *)aligned_alloc(32, bytes);
-    sim->sm = (float *)aligned_alloc(32, bytes);
+    size_t bytes = ((size_t)(sim->capacity ? sim->capacity : V) * sizeof(float) + 63u) / 64u * 64u;
+    sim->sx = (float *)aligned_alloc(64, bytes);
+    sim->sy = (float *)aligned_alloc(64, bytes);
+    sim->sm = (float *)aligned_alloc(64, bytes);
     NB_CHECK(sim->sx && sim->sy && sim->sm, "Failed to alloc snapshot for %u sources", mass_len);
     return sim;
 }
@@ -119,6 +148,20 @@ static inline void euler(Particle *p, float ax, float ay, float dt) {
     p->pos = AddV2(p->pos, ScaleV2(p->vel, dt));
 }
 
+#ifdef NB_CPU_RSQRT
+/* informational only: y ~ 1/sqrt(r2) by the hardware estimate, one Newton step y (1.5 - 0.5 r2 y^2), f = gm y^3 */
+#define PAIR_TERM(X, Y, R, AX, AY)                                                               \
+    do {                                                                                         \
+        vf dx = vf_sub(px, X);                                                                   \
+        vf dy = vf_sub(py, Y);                                                                   \
+        vf r2 = vf_add(vf_add(vf_mul(dx, dx), vf_mul(dy, dy)), R);                               \
+        vf y = vf_rsqrt(r2);                                                                     \
+        y = vf_mul(y, vf_sub(vf_set1(1.5f), vf_mul(vf_mul(vf_set1(0.5f), r2), vf_mul(y, y))));   \
+        vf f = vf_mul(gm, vf_mul(y, vf_mul(y, y)));                                              \
+        AX = vf_add(AX, vf_mul(dx, f));                                                          \
+        AY = vf_add(AY, vf_mul(dy, f));                                                          \
+    } while (0)
+#else
 #define PAIR_TERM(X, Y, R, AX, AY)                          \
     do {                                                    \
         vf dx = vf_sub(px, X);                              \
@@ -130,6 +173,7 @@ static inline void euler(Particle *p, float ax, float ay, float dt) {
         AX = vf_add(AX, vf_mul(dx, f));                     \
         AY = vf_add(AY, vf_mul(dy, f));                     \
     } while (0)
+#endif
 
 void CpuSimStep(CpuSim *sim, Particle *arr, uint32_t total_len, uint32_t mass_len, float dt) {
     const uint32_t padded = (mass_len + V - 1u) / V * V;

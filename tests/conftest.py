@@ -22,6 +22,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Wall-clock assertions run after every correctness row, whatever the files are called: the driver runs the GPU
+    suite with -x, and a slow box must not leave oracle / fixture / transport tests untested."""
+    perf = [it for it in items if it.fspath.basename == "test_gpu_zz_perf.py"]
+    if perf:
+        items[:] = [it for it in items if it.fspath.basename != "test_gpu_zz_perf.py"] + perf
+
+
 @pytest.fixture(scope="session")
 def manifest():
     with open(os.path.join(GOLDEN, "manifest.json")) as f:

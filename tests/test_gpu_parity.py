@@ -1508,65 +1508,6 @@ def test_rccl_watchdog_arms_per_wait_and_fires_on_a_wait_that_overruns(golden):
     assert "[watchdog] rank 0 of 1" in late.stderr and "did not complete within 2 s" in late.stderr
 
 
-def _replay_us_per_step(part, m, steps=100, **knobs):
-    """Fastest of three replays of a cached `steps`-step hipGraph chain, microseconds per step (wall clock of the blocking
-    PerformSimUpdate call, like nbody-bench)."""
-    sim = nb.SimPipeline(part.shape[0], m)
-    sim.configure(graph=1, **knobs)
-    sim.set_data(part)
-    sim.update(steps, 0.01)            # builds and instantiates the chain
-    best = float("inf")
-    for _ in range(3):
-        t0 = time.perf_counter()
-        sim.update(steps, 0.01)
-        best = min(best, (time.perf_counter() - t0) / steps * 1e6)
-    shape = sim.launch_shape()
-    sim.close()
-    return best, shape
-
-
-@pytest.mark.parametrize("n", [2000, 10000, 20000, 65536])
-def test_auto_launch_shape_is_near_the_best_of_its_neighbours_on_this_box(n):
-    """Ask the hardware, not the scan file: below N ~ 65 000 ten fitted constants and five thresholds pick every launch
-    shape (kernels.hip small_launch_cost_us / lane_split_rule), and the CPU tests pin them to the scans they were fitted
-    on.  Here the auto pick and its explicit neighbours (k, w, split around it; lane-split variants where they apply) are
-    timed on whatever box and runtime the suite landed on; auto more than 10 % slower than the best neighbour fails."""
-    _, part, m = bench_universe(n)
-    auto_us, auto = _replay_us_per_step(part, m)
-    rows = [("auto", auto_us, auto)]
-    seen = set()
-    if auto["lanes"] > 1 or n <= 4000:
-        for lanes, w in ((2, 16), (4, 8), (4, 16), (8, 8), (8, 16)):
-            us, sh = _replay_us_per_step(part, m, lanes=lanes, w=w)
-            rows.append((f"lanes={lanes} w={w}", us, sh))
-        base = nb.plan_launch(n, m)     # the classic plan (what auto falls back to when lanes=1)
-        k0, w0, s0 = base["k"], base["w"], base["split"]
-    else:
-        k0, w0, s0 = auto["k"], auto["w"], auto["split"]
-    for k in (1, 2):
-        for w in sorted({max(4, w0 // 2), w0, min(16, w0 * 2)}):
-            for split in sorted({max(1, (s0 * 3) // 4), s0, min(16, (s0 * 4 + 2) // 3)}):
-                if (k, w, split) in seen:
-                    continue
-                seen.add((k, w, split))
-                us, sh = _replay_us_per_step(part, m, k=k, w=w, split=split, lanes=1)
-                rows.append((f"k={k} w={w} split={split}", us, sh))
-    # the first pipeline of the test also carries the box's clock ramp (N = 20 000: 47.7 us first, 45.2 for the very same
-    # shape a second later): auto is timed again at the end and the faster of the two counts
-    again_us, _ = _replay_us_per_step(part, m)
-    auto_us = min(auto_us, again_us)
-    rows[0] = ("auto", auto_us, auto)
-    # the finish mode is an auto pick too (fused from N x M >= 4e7): the same shape with the finish kernel brought back
-    if auto["split"] > 1 and auto["lanes"] == 1:
-        us, sh = _replay_us_per_step(part, m, fused_finish=0)
-        rows.append(("auto, two-kernel finish", us, sh))
-    best = min(r[1] for r in rows)
-    print(f"\nN={n} M={m}: auto {auto} = {auto_us:.2f} us/step; best {best:.2f}")
-    for name, us, sh in sorted(rows, key=lambda r: r[1]):
-        print(f"  {name:22s} {us:9.2f} us/step  ({us / best - 1:+6.1%})  unit={sh['unit']} workgroups={sh['workgroups']}")
-    assert auto_us <= 1.10 * best, f"auto is {auto_us / best - 1:.1%} off the best neighbour at N={n}"
-
-
 def test_explicit_lanes_or_route_keeps_the_per_step_kernel_on_tiny_worlds():
     """"fused_chain" auto applies only while the launch shape is on auto -- an explicit lanes / variant asks for
     the per-step kernel also on a world small enough for the one-workgroup chain."""
@@ -1882,18 +1823,6 @@ print("NOT REACHED")
 # measurement aids: the clock probe and the clock sampler (include/nbody_hip.h; bench.py roofline.held_clock_ghz)
 # ---------------------------------------------------------------------------------------------------------------
 
-def test_clock_probe_reads_a_plausible_clock_and_the_instruction_mix_floor():
-    """nb_hip_probe_clock: the step kernels' interaction statement alone, 8 waves per SIMD on every CU.  The clock must be a
-    gfx950 shader clock (between 1.2 and the 2.4 GHz maximum, MI355X_MICROARCH.md) and the loop must run at the floor of
-    its instruction mix: 26 cycles per wave-interaction (9 plain fp32 VALU x 2 + one v_rsq_f32 x 8), within ramp and
-    arbitration losses -- which is what DESIGN.md prices the step kernel against."""
-    p = nb.probe_clock(20.0)
-    assert p["waves"] == 8192, p
-    assert 1.2 <= p["clock_ghz_min"] <= p["clock_ghz"] <= p["clock_ghz_max"] <= 2.45, p
-    assert 25.9 <= p["cycles_per_wave_interaction"] <= 29.0, p
-    assert 10.0 <= p["elapsed_ms"] <= 60.0, p
-
-
 def test_clock_sampler_runs_beside_the_step_kernels_without_touching_their_results():
     """nb_hip_clock_sampler_*: eight one-wave workgroups stamp the shader clock while a step chain runs on the pipeline's own
     stream.  The chain's results are bit-identical with and without the sampler, the sampler covers the chain's span, sits
@@ -1912,13 +1841,12 @@ def test_clock_sampler_runs_beside_the_step_kernels_without_touching_their_resul
     assert s["intervals"] >= 8 and 1.0 <= s["clock_ghz_min"] <= s["clock_ghz"] <= s["clock_ghz_max"] <= 2.45, s
     assert s["span_ms"] >= 5.0 and sum(1 for v in s["per_xcd_ghz"] if v > 0) >= 2, s
     assert all(1.0 <= v <= 2.45 for v in s["profile_ghz"]), s
-    # bounded: never stopped from the host, the waves leave after max_ms by themselves (end() then only collects)
-    import time
+    # bounded: never stopped from the host, the waves leave after max_ms by themselves (end() then only collects; how long
+    # that takes is asked in tests/test_gpu_zz_perf.py)
     nb.clock_sampler_begin(0.2, 100.0)
     time.sleep(0.5)
-    t0 = time.perf_counter()
     late = nb.clock_sampler_end()
-    assert time.perf_counter() - t0 < 0.2 and 80.0 <= late["span_ms"] <= 140.0, late
+    assert late["intervals"] >= 8 and late["span_ms"] >= 50.0, late
 
 
 @pytest.mark.skipif(not nb.hip_lib().nb_hip_tuning_build(), reason="the persistent-launch experiment kernels are built with make TUNING=1 only")
@@ -1988,10 +1916,8 @@ def test_bench_shard_leg_times_every_ranks_step_and_stamps_it(ranks):
     one.close()
     e = bench.shard_leg(nb, f"S{ranks}", part, m, ranks, 3, t1_ms=t1_ms)
     k = e["shard_kernel_ms_per_step"]
-    assert e["ranks"] == ranks and 0 < k["min"] <= k["mean"] <= k["max"] < t1_ms        # a shard's step is shorter than the whole step
-    assert k["max"] >= 0.5 * t1_ms / ranks                                               # ... and not shorter than its share allows
-    assert 0.4 <= e["compute_scaling_efficiency"] <= 1.2, e
-    assert e["all_shards_wall_ms_per_step"] >= ranks * k["min"] * 0.9
+    assert e["ranks"] == ranks and 0 < k["min"] <= k["mean"] <= k["max"]                 # every member's kernels were timed
+    assert e["single_gpu_ms_per_step"] == t1_ms and e["compute_scaling_efficiency"] > 0  # (how the times relate: test_gpu_zz_perf.py)
     p = e["parity"]
     assert p["worst_ratio"] <= 1.0 and p["integrator_bit_exact"] and p["static_fields_equal"], p
     plan = nb.shard_plan(n, m, 0, ranks)

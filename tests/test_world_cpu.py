@@ -230,3 +230,43 @@ def test_float64_truth_build_of_the_cpu_stepper(golden, n):
     assert np.array_equal(got[:, 2:4], v) and np.array_equal(got[:, 0:2], part[:, 0:2] + v * np.float32(0.01))
     avx = ob.step(part, m, 0.01, 1)
     assert np.all(np.abs(avx[:, 4:6].astype(np.float64) - acc64) <= 1e-4 * np.abs(acc64) + 1e-6 * mag)
+
+
+@pytest.mark.parametrize("isa", ["avx2fma", "avx2fma_rsqrt", "avx512", "avx512_rsqrt"])
+@pytest.mark.parametrize("n", [333, 4096])
+def test_informational_cpu_variants_stay_within_the_fp32_tolerance(golden, isa, n):
+    """libnbody_cpu_best.so (csrc/cpu_best.c; SURVEY.md 8d "best CPU" row; the reference's SIMD matrix is
+    src/lib/CMakeLists.txt:24-33): sim_cpu.c built with FMA contraction / 16 lanes / rsqrt estimate + Newton.  None is
+    bit-exact with a reference build -- and must not claim to be -- but each sits within the stated one-step tolerance
+    of the float64 sum (1e-4 |acc| + 1e-6 sum |contribution|), integrates its own acc like the reference does up to the
+    one rounding an FMA saves (contraction is allowed in these builds, as under -march=native), passes mass / radius
+    through, and a variant this CPU cannot run is refused, not emulated."""
+    table = {name: ok for name, ok, _ in nb.cpu_variants()}
+    assert set(table) == {"avx2fma", "avx2fma_rsqrt", "avx512", "avx512_rsqrt"}
+    part, m = ob.partition(golden(f"ic_{n}.bin"))
+    if not table[isa]:
+        with pytest.raises(RuntimeError):
+            nb.cpu_variant_update(isa, part, m, 0.01, 1)
+        pytest.skip(f"this CPU does not run {isa}")
+    got = nb.cpu_variant_update(isa, part, m, 0.01, 1)
+    acc64, mag = ob.acc_f64(part, m)
+    assert np.all(np.abs(got[:, 4:6].astype(np.float64) - acc64) <= 1e-4 * np.abs(acc64) + 1e-6 * mag)
+    dt64, eps = float(np.float32(0.01)), 2.0 ** -23     # one fp32 rounding of each operand's magnitude covers FMA or mul + add
+    v0, a = part[:, 2:4].astype(np.float64), got[:, 4:6].astype(np.float64)
+    assert np.all(np.abs(got[:, 2:4] - (v0 + a * dt64)) <= eps * (np.abs(v0) + np.abs(a * dt64)))
+    p0, v1 = part[:, 0:2].astype(np.float64), got[:, 2:4].astype(np.float64)
+    assert np.all(np.abs(got[:, 0:2] - (p0 + v1 * dt64)) <= eps * (np.abs(p0) + np.abs(v1 * dt64)))
+    assert np.array_equal(got[:, 6:8], part[:, 6:8])
+    assert not np.array_equal(got[:, 4:6], ob.step(part, m, 0.01, 1)[:, 4:6])      # informational: NOT the reference's bits
+    # ten steps: relative to what the steps moved, like the GPU suite's multi-step bound
+    want = ob.step(part, m, 0.01, 10)
+    got10 = nb.cpu_variant_update(isa, part, m, 0.01, 10)
+    p0 = part[:, 0:2].astype(np.float64)
+    dg, dw = got10[:, 0:2] - p0, want[:, 0:2] - p0
+    assert np.linalg.norm(dg - dw) / np.linalg.norm(dw) <= 1e-4
+
+
+def test_unknown_cpu_variant_is_refused(golden):
+    part, m = ob.partition(golden("ic_333.bin"))
+    with pytest.raises(RuntimeError):
+        nb.cpu_variant_update("avx1024", part, m, 0.01, 1)

@@ -48,7 +48,7 @@ python bench.py --gpus 3 --transport direct --steps 10 --warmup 2 --extra-partic
   done
 } > $O/${TAG}_nbody_bench_ranks.txt 2>&1; echo "C ranks rc=$?"
 python tools/gpu_vs_avx.py > $O/${TAG}_gpu_vs_avx.txt 2>&1; echo "gpu-vs-avx rc=$?"
-python -m pytest tests/test_gpu_parity.py -q -s -m gpu -k near_the_best > $O/${TAG}_auto_vs_neighbours.txt 2>&1; echo "auto-vs-neighbours rc=$?"
+python -m pytest tests/test_gpu_zz_perf.py -q -s -m gpu -k near_the_best > $O/${TAG}_auto_vs_neighbours.txt 2>&1; echo "auto-vs-neighbours rc=$?"
 [ "$FULL" = "full" ] || exit 0
 {
   echo "== tools/frame_probe.py: the reference GUI's frame loop through include/nbody.h (300 frames each), defaults =="
