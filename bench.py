@@ -61,14 +61,25 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_INTERACTION = 14        # reference op count, sim_cpu.c:169-188
-PEAK_FP32_VECTOR_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)"
+from nbody_amd.benchlib import (FLOP_PER_INTERACTION, GATHER_LATENCY_ASSUMED_MS, PEAK_FP32_VECTOR_TFLOPS, XGMI_LINK_GBS,  # noqa: E402,F401
+                                algorithmic_bytes_per_launch, cpu_model, device_cus, gather_estimate_ms, held_clock_fields,
+                                host_cores, host_cpu_share, kernel_sources_sha, libgomp, pmc_traffic, pmc_traffic_parts)
+from nbody_amd.launch import LastGasp, LegGuard, headline_of as _headline_of, supervise  # noqa: E402,F401
+
 N_PARTICLES = 1 << 20
 N_CONFIG5 = 1 << 22
 N_CONFIG2 = 1 << 16
 N_CONFIG3 = 1 << 18
 DT = 0.01
-KERNEL_SOURCES = ("nbody_amd/csrc/kernels.hip", "nbody_amd/csrc/kernels.h", "nbody_amd/csrc/interaction_asm.h")
+
+# Announcements of what the run is about to do.  EMPTY in every real run; tests/bench_rehearsal.py (imported only when
+# NB_BENCH_REHEARSE is set) registers observers that make a chosen failure happen at a chosen place.
+OBSERVERS = []
+
+
+def notify(event, **info):
+    for observer in OBSERVERS:
+        observer(event, info)
 
 
 def make_workload(n, all_massive=False):
@@ -90,60 +101,12 @@ def make_workload(n, all_massive=False):
 
 # ---- CPU baseline ---------------------------------------------------------------------------------------------------
 
-def host_cpu_share():
-    """How many host threads the CPU legs may use, and why.  Derived from what the process is allowed to run on -- the
-    scheduler affinity mask and, where the container sets one, the cgroup CPU quota -- not from a literal.  Only when
-    neither narrows a big host (affinity == every core of a > 32-core machine, no quota) does the pool's documented share
-    apply (one GPU of this pool comes with 16 CPUs); NB_BENCH_CPU_THREADS overrides everything.  Everything consulted is
-    recorded on the line."""
-    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
-    count = os.cpu_count() or 1
-    quota = None
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:      # cgroup v2: "<quota> <period>" or "max <period>"
-            q, per = f.read().split()[:2]
-            if q != "max":
-                quota = max(1, int(float(q) / float(per) + 0.5))
-    except (OSError, ValueError):
-        try:
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
-                q, per = int(f.read()), int(g.read())
-                if q > 0 and per > 0:
-                    quota = max(1, int(q / per + 0.5))
-        except (OSError, ValueError):
-            pass
-    threads, why = (affinity or count), "sched_getaffinity"
-    if quota is not None and quota < threads:
-        threads, why = quota, "cgroup cpu quota"
-    if why == "sched_getaffinity" and threads == count and count > 32:
-        threads, why = 16, "pool share (16 CPUs per GPU box; affinity and cgroup quota leave all %d cores open)" % count
-    env = os.environ.get("NB_BENCH_CPU_THREADS")
-    if env and env.isdigit() and int(env) > 0:
-        threads, why = int(env), "NB_BENCH_CPU_THREADS"
-    return {"threads": max(1, threads), "threads_from": why, "affinity_cores": affinity, "os_cpu_count": count,
-            "cgroup_cpu_quota": quota, "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS")}
-
-
-def host_cores():
-    return host_cpu_share()["threads"]
-
-
-def _libgomp():
-    for name in ("libgomp.so.1", "libgomp.so"):
-        try:
-            return C.CDLL(name)
-        except OSError:
-            pass
-    return None
-
-
 def cpu_baseline(part, mass_len, budget_s=12.0):
     """The reference's own UpdateWorld_CPU (src/lib/world.c:99-110: PackParticles + the OpenMP schedule(static, 20) loop
     over PackedUpdate, src/lib/sim_cpu.c:156-194), compiled where it lies into oracle/_ref/libnbody_ref_world.so, timed
     on this box's host cores over a bounded sample of the same workload; beside it the product's UpdateWorld_CPU on the
-    same World with the same number of threads.  Fallbacks, in order, when that library is absent: the
-    reference's PackedUpdate object code driven per receiver from Python threads (oracle/_ref/libnbody_ref_cpu.so), then
-    the oracle's AVX restatement (kind "port")."""
+    same World with the same number of threads, and -- informational -- the fastest of the product's CPU variants this
+    host runs (`best_cpu`).  When oracle/_ref is absent: the oracle's AVX restatement (kind "port")."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
 
@@ -173,14 +136,6 @@ def cpu_baseline(part, mass_len, budget_s=12.0):
         except Exception as e:  # pragma: no cover - diagnostic only
             print(f"[bench] reference UpdateWorld_CPU leg failed ({e}); falling back", file=sys.stderr)
             sec = None
-    if sec is None and os.path.exists(ob.REF_CPU_SO):
-        try:
-            sec = _time_reference_packedupdate(ob.REF_CPU_SO, part, mass_len, recv, cores)
-            kind = "reference"
-            how = "reference PackedUpdate object code (oracle/_ref/libnbody_ref_cpu.so) driven per receiver from Python threads"
-        except Exception as e:  # pragma: no cover - diagnostic only
-            print(f"[bench] reference PackedUpdate leg failed ({e}); using the port", file=sys.stderr)
-            sec = None
     if sec is None:
         sec, threads, _ = ob.time_avx_sample(part, mass_len, 0, recv, dt=DT, threads=cores)
         how = "oracle/nbody_oracle.c AVX restatement (bit-exact with the reference's AVX build)"
@@ -190,16 +145,17 @@ def cpu_baseline(part, mass_len, budget_s=12.0):
         "cores": threads,
         "kind": kind,
         "how": how,
-        "cpu_model": _cpu_model(),
+        "cpu_model": cpu_model(),
         "value_1_thread": one,
         "sample": f"World of the first {recv} of {n} partitioned particles (all {mass_len} sources), one step, AVX (-mavx, no FMA) "
                   f"+ {threads} threads ({sec:.2f} s); the whole step would take ~{sec * n / recv:.0f} s",
     }
     out.update({k: share[k] for k in ("threads_from", "affinity_cores", "os_cpu_count", "cgroup_cpu_quota", "OMP_NUM_THREADS")})
-    try:
-        out["product"] = product_cpu_leg(part, mass_len, recv, threads)
-    except Exception as e:  # pragma: no cover - diagnostic only
-        out["product"] = {"error": str(e)}
+    for key, leg in (("product", product_cpu_leg), ("best_cpu", best_cpu_leg)):
+        try:
+            out[key] = leg(part, mass_len, recv, threads)
+        except Exception as e:  # pragma: no cover - diagnostic only
+            out[key] = {"error": str(e)}
     return out
 
 
@@ -218,7 +174,7 @@ def _time_reference_world(so, part, recv, threads, steps=1):
     ref.UpdateWorld_CPU.argtypes = [C.c_void_p, C.c_float, C.c_uint32]
     ref.DestroyWorld.restype = None
     ref.DestroyWorld.argtypes = [C.c_void_p]
-    gomp = _libgomp()
+    gomp = libgomp()
     if gomp is not None:
         gomp.omp_set_num_threads(C.c_int(threads))
     sample = np.ascontiguousarray(part[:recv])
@@ -238,7 +194,7 @@ def product_cpu_leg(part, mass_len, recv, threads):
     import nbody_amd as nb
 
     recv = max(recv, mass_len)  # the sources must all be in the World
-    gomp = _libgomp()
+    gomp = libgomp()
     if gomp is not None:
         gomp.omp_set_num_threads(C.c_int(threads))
     w = nb.World(part[:recv])
@@ -253,45 +209,37 @@ def product_cpu_leg(part, mass_len, recv, threads):
             "sample": f"World of the first {recv} partitioned particles (all {mass_len} sources), one UpdateWorld_CPU step ({sec:.2f} s)"}
 
 
-def _cpu_model():
-    try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("model name"):
-                    return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return None
-
-
-def _time_reference_packedupdate(so, part, mass_len, recv, cores):
-    """oracle/_ref = the reference's own sim_cpu.c, driven like world.c:101-107 from `cores` threads."""
-    from concurrent.futures import ThreadPoolExecutor
-
-    ref = C.CDLL(so)
-    ref.AllocPackArray.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_uint32]
-    ref.PackParticles.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
-    ref.PackedUpdate.argtypes = [C.c_void_p, C.c_float, C.c_uint32, C.c_void_p]
-    ref.FreePackArray.argtypes = [C.c_void_p]
-    pack, plen = C.c_void_p(), C.c_uint32()
-    ref.AllocPackArray(C.byref(pack), C.byref(plen), mass_len)
-    ref.PackParticles(mass_len, part.ctypes.data, pack)
-    scratch = part[:recv].copy()
-    base = scratch.ctypes.data
-
-    def work(t):
-        for i in range(t, recv, cores):
-            ref.PackedUpdate(base + 32 * i, DT, plen.value, pack)  # releases the GIL
-
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(work, range(cores)))
-    sec = time.perf_counter() - t0
-    ref.FreePackArray(pack)
-    return sec
-
-
 # ---- parity stamp ----------------------------------------------------------------------------------------------------
+
+def best_cpu_leg(part, mass_len, recv, threads):
+    """SURVEY.md 8d's informational "best CPU" row: the product's sim_cpu.c built for what the host cores can do (FMA
+    contraction, 16 lanes, rsqrt estimate + Newton: nbody_amd/csrc/cpu_best.c; the reference's whole SIMD matrix is
+    src/lib/CMakeLists.txt:24-33), every variant this CPU runs timed on the same one-step sample with the same threads.
+    NOT bit-exact with any reference build -- within the stated fp32 tolerance (tests/test_world_cpu.py) -- and never the
+    stated baseline: that stays the -mavx reference row."""
+    import nbody_amd as nb
+
+    recv = max(recv, mass_len)
+    gomp = libgomp()
+    if gomp is not None:
+        gomp.omp_set_num_threads(C.c_int(threads))
+    sample = np.ascontiguousarray(part[:recv])
+    rates, skipped = {}, []
+    for isa, runs_here, _what in nb.cpu_variants():
+        if not runs_here:
+            skipped.append(isa)
+            continue
+        t0 = time.perf_counter()
+        nb.cpu_variant_update(isa, sample, mass_len, DT, 1)
+        rates[isa] = recv * mass_len / (time.perf_counter() - t0)
+    if not rates:
+        return {"value": None, "note": "this CPU runs none of the variants", "not_supported_here": skipped}
+    best = max(rates, key=rates.get)
+    return {"value": rates[best], "unit": "interactions/s", "isa": best, "cores": threads, "variants": rates, "not_supported_here": skipped,
+            "what": dict((i, w) for i, _, w in nb.cpu_variants())[best],
+            "note": "not bit-exact with the reference; informational (within the stated fp32 tolerance of the float64 sum); "
+                    "the stated baseline is the -mavx reference row above"}
+
 
 def parity_stamp(sim, mass_len, dt=DT, samples=256):
     """What the line says about the correctness of what it timed.  Reads the state S the timed steps left, runs ONE more
@@ -338,192 +286,6 @@ def parity_stamp(sim, mass_len, dt=DT, samples=256):
                     "gpu_vs_avx_max = |acc_gpu - acc_avx| / sum|contrib|; integrator identity over all particles"}
 
 
-# ---- roofline.traffic: tied to the committed PMC profile ----------------------------------------------------------------
-
-def kernel_sources_sha():
-    """sha256 over the kernel sources with comments and blank space removed (editing a comment must not orphan a
-    profile); with the launch shape and the source passes per step (both decided in step_chain.hip, both recorded next
-    to the figure) it is what a committed PMC traffic figure is tied to."""
-    import re
-
-    h = hashlib.sha256()
-    for rel in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, rel), "r") as f:
-            text = f.read()
-        text = re.sub(r"// NB_HASH_OFF.*?// NB_HASH_ON[^\n]*", "", text, flags=re.S)   # host-side cost model (which shape
-        #                                     it picks is recorded separately, under "launch")
-        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)     # block comments
-        text = re.sub(r"//[^\n]*", "", text)                   # line comments (no string in these files holds "//")
-        text = "\n".join(line.strip() for line in text.splitlines() if line.strip())
-        h.update(text.encode())
-    return h.hexdigest()
-
-
-def _pmc_record(n, shape=None, passes=None):
-    """(record, note): the committed PMC profile, or None and why it does not apply to this run."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(p):
-        return None, "no committed PMC profile"
-    with open(p) as f:
-        rec = json.load(f)
-    if rec.get("n") not in (None, n):
-        return None, f"committed PMC profile is for N={rec.get('n')}"
-    want = rec.get("launch")
-    if want is not None and shape is not None:
-        got = dict(shape, passes=passes)
-        if any(got.get(key) != val for key, val in want.items()):
-            return None, f"stale: this run launched {got}, the PMC profile {rec.get('source')} was taken with {want}"
-    if rec.get("kernel_sources_sha256") != kernel_sources_sha():
-        return None, ("stale: kernel sources changed since the PMC profile " + str(rec.get("source"))
-                      + " was taken (tools/profile.sh + tools/summarize_profile.py refresh it)")
-    return rec, f"from {rec.get('source')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, same sources)"
-
-
-def pmc_traffic(n, shape=None, passes=None):
-    """(HBM bytes per step-kernel launch, note): rocprofv3 PMC passes cannot run inside this process, so the figure comes
-    from the committed profile -- and only counts while the kernel sources still hash to what was profiled and this run
-    launched the same shape with the same number of source passes."""
-    rec, note = _pmc_record(n, shape, passes)
-    return (rec.get("hbm_bytes_per_launch") if rec else None), note
-
-
-def pmc_traffic_parts(n, shape=None, passes=None):
-    """The same figure taken apart: FETCH_SIZE as counted (raw), with the guide's x2, and WRITE_SIZE -- so a reader can
-    see which part of `traffic` is a measurement and which a correction."""
-    rec, _ = _pmc_record(n, shape, passes)
-    if not rec or "fetch_bytes_raw" not in rec:
-        return None
-    return {"fetch_raw": rec["fetch_bytes_raw"], "fetch_corrected_x2": 2.0 * rec["fetch_bytes_raw"], "write": rec["write_bytes"],
-            "raw_total": rec["fetch_bytes_raw"] + rec["write_bytes"],
-            "note": "traffic = 2 x FETCH_SIZE + WRITE_SIZE.  MI355X_MICROARCH.md calibrates the x2 on 16-B-per-lane "
-                    "coalesced streaming loads; this kernel's global loads are 8-B float2 / 4-B float per lane plus the "
-                    "scalar cache's 64-B line fills (uncalibrated widths), so the corrected figure is an upper bound and "
-                    "raw_total a lower bound.  Either way ~1-2 GB/s of ~8000: HBM does not bound this kernel."}
-
-
-def algorithmic_bytes_per_launch(n, m, passes):
-    """DESIGN.md section 3 'Algorithmic bytes': per step, reads N*(pos 8 + radius 4) per pass + acc 8 per chained pass
-    + vel 8 + M*(x, y, G*m) 12; writes acc 8 per pass + vel 8 + pos 8.  Mean per launch (= per pass)."""
-    reads = n * (12 * passes + 8 * (passes - 1) + 8) + m * 12
-    writes = n * (8 * passes + 16)
-    return (reads + writes) / passes
-
-
-MIX_FLOOR_CYCLES = 26.0   # 9 plain fp32 VALU instructions at 2 issue cycles + one v_rsq_f32 at 8 (DESIGN.md section 3)
-NOMINAL_CLOCK_GHZ = 2.4   # MI355X_MICROARCH.md "Max clock"; the 157.3 TFLOP/s peak is quoted at it
-
-
-def device_cus(device_info):
-    """Compute units out of nb_hip_device_info's "name arch CUs clockMHz pci=..." (the token after the gfx arch)."""
-    tok = str(device_info).split()
-    for i, t in enumerate(tok):
-        if t.startswith("gfx") and i + 1 < len(tok) and tok[i + 1].isdigit():
-            return int(tok[i + 1])
-    return 256
-
-
-def held_clock_fields(probe, sampled, per_launch_s, launch_interactions, device_info, achieved_tflops):
-    """roofline.held_clock_ghz and what follows from it: how many shader cycles one wave-interaction of the TIMED kernel
-    took on every SIMD (kernel seconds x held clock x SIMDs / wave-interactions), which fraction of the instruction mix's
-    26-cycle floor that is, and the roofline fraction re-priced at the held clock instead of the nominal 2.4 GHz.
-    `sampled` (preferred): the clock sampler's reading during a repeat of the same K steps -- the clock the chip holds
-    under the step kernel itself.  `probe`: the separate probe kernel run right after the headline leg; its loop is denser
-    than the step kernel's, so the chip holds a lower clock for it -- kept on the line as the pure-loop reference."""
-    out = {"held_clock_ghz": None, "clock_probe": probe, "clock_sampled": sampled}
-    ghz, source, slowest = None, None, None
-    if sampled and sampled.get("clock_ghz"):
-        per_xcd = [v for v in sampled.get("per_xcd_ghz", []) if v > 0]
-        # every XCD computes an eighth of a launch (the dispatcher deals workgroups round-robin to the XCDs), so the chip's
-        # clock is the mean over the XCDs -- and the launch ends with its slowest XCD
-        ghz = sum(per_xcd) / len(per_xcd) if per_xcd else sampled["clock_ghz"]
-        slowest = min(per_xcd) if per_xcd else None
-        source = ("clock sampler during a repeat of the same K steps (8 one-wave workgroups, one per XCD, stamping s_memtime / "
-                  "s_memrealtime every 0.5 ms on their own stream, outside the headline's timed region); mean of the per-XCD medians")
-    elif probe and probe.get("clock_ghz"):
-        ghz, source = probe["clock_ghz"], "probe kernel right after the headline leg (reads LOW: its loop is denser than the step kernel's)"
-    if ghz is None or per_launch_s <= 0 or launch_interactions <= 0:
-        return out
-    simds = 4 * device_cus(device_info)
-    cycles = per_launch_s * ghz * 1e9 * simds / (launch_interactions / 64.0)
-    out.update({
-        "held_clock_ghz": ghz,
-        "held_clock_source": source,
-        "cycles_per_wave_interaction": cycles,
-        "frac_of_mix_ceiling": MIX_FLOOR_CYCLES / cycles,
-        "held_clock_ghz_slowest_xcd": slowest,
-        # workgroups are dealt to the XCDs in equal shares, so a launch lasts as long as its slowest XCD needs
-        "cycles_per_wave_interaction_slowest_xcd": cycles * slowest / ghz if slowest else None,
-        "frac_at_held_clock": achieved_tflops / (PEAK_FP32_VECTOR_TFLOPS * ghz / NOMINAL_CLOCK_GHZ),
-        # one wave-interaction = 14 x 64 counted flops; the peak is 64 flop per cycle and SIMD (157.3e12 / 1024 / 2.4e9)
-        "mix_ceiling_frac_at_nominal_clock": FLOP_PER_INTERACTION / MIX_FLOOR_CYCLES,
-        "cycles_note": f"cycles_per_wave_interaction = headline kernel seconds per launch x held clock x {simds} SIMDs / wave-interactions "
-                       f"per launch; floor of this instruction mix = {MIX_FLOOR_CYCLES:g} cycles (9 plain fp32 VALU x 2 + v_rsq_f32 x 8)",
-    })
-    return out
-
-
-# ---- deadline guard of the optional legs --------------------------------------------------------------------------------
-
-class LastGasp:
-    """The optional legs can also die the hard way: the library's error convention is the reference's -- print and abort()
-    (src/lib/util.h:17-29) -- and RCCL inside stream capture with several ranks has never run anywhere.  A fatal signal
-    raised inside a C call never reaches a Python-level handler, so rank 0 registers a C one while optional legs run
-    (nbody_amd/csrc/last_gasp.c -> lib/libnb_lastgasp.so): on SIGABRT / SIGSEGV / SIGBUS / SIGFPE it write()s the line
-    prepared when the current leg was armed -- headline + self-check + the legs finished so far + "extras_aborted" -- and
-    _exit(6)s.  The handler is plain C doing only async-signal-safe calls on bytes copied beforehand: no GIL, no
-    allocation, no Python in signal context."""
-
-    def __init__(self, fd):
-        self.fd = fd
-        self._lib = C.CDLL(os.path.join(ROOT, "nbody_amd", "lib", "libnb_lastgasp.so"))
-        self._lib.nb_last_gasp_set.argtypes = [C.c_int, C.c_char_p, C.c_ulong]
-        self._lib.nb_last_gasp_set.restype = C.c_int
-
-    def arm(self, line_bytes):
-        if self._lib.nb_last_gasp_set(self.fd, line_bytes, len(line_bytes)) != 0:
-            print("[bench] last-gasp line too long; keeping the previous one", file=sys.stderr)
-
-    def disarm(self):
-        self._lib.nb_last_gasp_disarm()
-
-
-class LegGuard:
-    """Host-side deadline around every optional leg.  The legs block inside C calls (ctypes releases the GIL), so a
-    Python thread can watch the clock: on expiry rank 0 writes the JSON line with what is in hand plus
-    "extras_aborted", and every rank leaves with os._exit(4) -- a fresh exit (the process has touched the GPU; no
-    re-exec, no retry).  The other ranks wait a moment first so that rank 0's line is out before the launcher reacts."""
-
-    def __init__(self, rank, emit_partial, default_s):
-        self.rank, self.emit_partial, self.default_s = rank, emit_partial, default_s
-        self.lock = threading.Lock()
-        self.leg, self.until = None, None
-        self.thread = threading.Thread(target=self._watch, daemon=True)
-        self.thread.start()
-
-    def arm(self, leg, seconds=None):
-        with self.lock:
-            self.leg, self.until = leg, time.monotonic() + (seconds if seconds else self.default_s)
-
-    def disarm(self):
-        with self.lock:
-            self.leg, self.until = None, None
-
-    def _watch(self):
-        while True:
-            time.sleep(0.2)
-            with self.lock:
-                leg, until = self.leg, self.until
-            if leg is None or time.monotonic() < until:
-                continue
-            print(f"[bench] rank {self.rank}: leg '{leg}' passed its deadline; writing what is in hand and exiting (4)",
-                  file=sys.stderr, flush=True)
-            if self.rank == 0:
-                self.emit_partial(leg)
-            else:
-                time.sleep(3.0)
-            os._exit(4)
-
-
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -533,13 +295,19 @@ def parse_args(argv=None):
                     help="particles (default 2^20, the size the metric is quoted on); not --n: torchrun claims that prefix")
     ap.add_argument("--extra-particles", dest="n5", type=int, default=N_CONFIG5,
                     help="size of the second sharded workload under extra_configs (default 2^22 = BASELINE.json config 5)")
-    ap.add_argument("--transport", choices=("auto", "rccl", "host", "direct"), default="auto",
-                    help="N > 1: auto (default) = rccl, and if any rank of that attempt leaves before the headline is in hand, a FRESH "
-                         "set of rank processes with the direct exchange (the line is stamped transport_fallback); "
-                         "rccl = in-stream ncclAllGather (the product path); direct = no RCCL: every rank pushes its slice "
-                         "device-to-device into its peers' IPC-mapped source arrays, one barrier per step over the rendezvous link "
-                         "(the fallback should RCCL not come up); host = data staged through the host over the rendezvous link "
-                         "(slow).  direct and host let several ranks share ONE GPU, where RCCL refuses duplicate devices")
+    ap.add_argument("--transport", choices=("auto", "rccl", "direct", "host"), default="auto",
+                    help="N > 1: auto (default) = rccl -> direct -> host: an attempt that does not deliver a verified headline (a rank "
+                         "that leaves during bring-up, a time-out, a failed self-check) is followed by a FRESH set of rank processes "
+                         "over the next transport, and the line says so (transport_fallback).  rccl = in-stream ncclAllGather (the "
+                         "product path); direct = no RCCL: every rank pushes its slice device-to-device into its peers' IPC-mapped "
+                         "source arrays, one host barrier per step; host = slices staged through the host over the rendezvous link "
+                         "(slow, but needs neither RCCL nor IPC: the transport nothing can refuse).  direct and host let several "
+                         "ranks share ONE GPU, where RCCL refuses duplicate devices")
+    ap.add_argument("--budget-s", type=float, default=480.0,
+                    help="total wall-clock budget of the run (default 480 s, below the 600 s a driver allows the command): N > 1: "
+                         "every attempt's limit, the rank link's timeout and the library's collective watchdog are carved from it and "
+                         "the headline leg runs under a deadline; 1 GPU: optional legs are skipped once it is used up.  When it "
+                         "expires the run still prints one line (value null if no headline was reached) and exits non-zero")
     ap.add_argument("--rendezvous", choices=("socket", "gloo"), default="socket",
                     help="N > 1: how the ranks meet on the host.  socket = a stdlib Unix-socket hub (no torch import: the run "
                          "binds /opt/rocm's HIP runtime and librccl); gloo = torch.distributed (torch's bundled runtime loads first)")
@@ -556,25 +324,10 @@ def parse_args(argv=None):
     ap.add_argument("--all-massive", action="store_true",
                     help="informational N^2 run: every particle is a source (not the BASELINE.json workload)")
     ap.add_argument("--dry-run", action="store_true",
-                    help="rehearse the multi-rank control flow (rendezvous, id broadcast, barriers, reductions, JSON keys) "
+                    help="walk the multi-rank control flow (rendezvous, id broadcast, barriers, reductions, JSON keys) "
                          "without touching a GPU: no step runs and the reported value is 0")
     ap.add_argument("--leg-deadline-s", type=float, default=120.0,
                     help="N > 1: host-side deadline of every optional leg (below the library's own 180 s collective watchdog)")
-    ap.add_argument("--stall-leg", default=None,
-                    help="rehearsal only (host transport): the all-gather callback never returns during this leg "
-                         "(overlap | sharded_graph | config5), to exercise the deadline path")
-    ap.add_argument("--crash-leg", default=None,
-                    help="rehearsal only: rank 0 abort()s inside this leg (N > 1, host transport: in the leg's all-gather; one GPU: "
-                         "at the start of the leg -- 'clock probe', 'parity stamp', 'repeats', 'clock sampler leg', 'alt_lds', "
-                         "'extra_configs C2/C3/N2/C1', 'extra_configs S2/S4/S8/C5S8'), to exercise the last-gasp line")
-    ap.add_argument("--rehearse-rccl-failure", action="store_true",
-                    help="rehearsal only: in an rccl attempt the last rank leaves with exit code 3 right after the rendezvous, like the "
-                         "library's watchdog does when ncclCommInitRank never completes -- exercises --transport auto's fallback")
-    ap.add_argument("--rehearse-hang", action="store_true",
-                    help="rehearsal only: every rank sleeps for a minute right after the rendezvous (a collective that never "
-                         "completes), to exercise the supervisor's clean-up when it is told to stop")
-    ap.add_argument("--attempt-timeout-s", type=float, default=900.0,
-                    help="N > 1: the supervisor ends (by exact pid) rank processes of an attempt that runs longer than this")
     return ap.parse_args(argv)
 
 
@@ -591,6 +344,12 @@ def worker_main(args):
     attempt = int(os.environ.get("NB_BENCH_ATTEMPT", "0"))
     if args.transport == "auto":
         args.transport = "rccl"   # the supervisor passes an explicit transport to every attempt; a lone rank has no fallback to make
+    # the run's budget as a point on CLOCK_MONOTONIC (one clock for every process of the box): handed down by the supervisor
+    # for this attempt, else counted from here
+    hard_deadline = float(os.environ.get("NB_BENCH_DEADLINE_MONO", 0.0)) or time.monotonic() + args.budget_s
+
+    def time_left():
+        return hard_deadline - time.monotonic()
 
     # stdout carries exactly one line, the JSON: RCCL prints a version banner to stdout from native code, so the
     # process' fd 1 is pointed at stderr for the duration and the line is written to the saved descriptor at the end
@@ -608,6 +367,40 @@ def worker_main(args):
 
     import nbody_amd as nb  # libnbody_hip.so is loaded at the first call; aborts later if no gfx950 answers
 
+    # ---- the line: one JSON object on rank 0, written once, whatever happens ------------------------------------
+    out = {}
+    out_lock = threading.Lock()
+    emitted = {"done": False}
+
+    def emit(extra_keys=None):
+        with out_lock:
+            if emitted["done"] or rank != 0:
+                return
+            emitted["done"] = True
+            line = dict(out)
+            if extra_keys:
+                line.update(extra_keys)
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+
+    def put(key, val):
+        if rank == 0:
+            with out_lock:
+                out[key] = val
+
+    def emit_partial(leg):
+        """A leg passed its deadline: the headline in hand goes out with the leg's name; without one, a line that says so."""
+        if "value" in out:
+            emit({"extras_aborted": leg})
+        else:
+            emit({"metric": "particle-pair interactions/sec at N=2^20", "value": None, "unit": "interactions/s", "n_gpus": world,
+                  "error": f"leg '{leg}' passed its deadline before a headline was in hand (budget {args.budget_s:g} s)"})
+
+    # every leg of a multi-rank run -- the headline included -- runs under a host-side deadline that never reaches past the
+    # budget: a bring-up that blocks (an IPC open, a first barrier) ends in a line and exit 4, not in the driver's kill
+    guard = LegGuard(rank, emit_partial, args.leg_deadline_s, hard_deadline - 3.0) if sharded and not args.dry_run else None
+    if guard:
+        guard.arm("headline (rendezvous, preflight, bring-up, timed steps)", max(5.0, time_left() - 3.0))
+
     # The ranks meet on the host only when launched through torch.distributed.run (also at world == 1, so that a
     # single-GPU box can rehearse the whole multi-rank flow with NB_HIP_FORCE_SHARDED=1): by default over a stdlib
     # socket hub, so that no torch -- and with it no second HIP runtime / librccl -- is in the process.
@@ -615,26 +408,19 @@ def worker_main(args):
     torch = None
     link = None
     if "RANK" in os.environ and "MASTER_PORT" in os.environ:
+        wait_s = max(5.0, time_left())
         if args.rendezvous == "gloo":
             import torch
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=900))
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=wait_s))
         else:
             from nbody_amd.ranklink import RankLink
 
-            link = RankLink(rank, world, name="nbody_bench_%s_%s_a%d" % (os.environ["MASTER_PORT"],
-                                                                        os.environ.get("TORCHELASTIC_RUN_ID", "none"), attempt))
-            if args.rehearse_hang:
-                link.barrier()
-                time.sleep(60.0)
-                os._exit(9)
-            if args.rehearse_rccl_failure and args.transport == "rccl" and world > 1:
-                link.barrier()
-                if rank == world - 1:
-                    print(f"[bench] rank {rank}: rehearsing an RCCL bootstrap that never completes: exit 3", file=sys.stderr, flush=True)
-                    os._exit(3)
+            link = RankLink(rank, world, timeout_s=wait_s, name="nbody_bench_%s_%s_a%d" % (
+                os.environ["MASTER_PORT"], os.environ.get("TORCHELASTIC_RUN_ID", "none"), attempt))
+        notify("rendezvous", link=link, rank=rank, world=world, transport=args.transport)
     elif world > 1:
         sys.exit("WORLD_SIZE > 1 without a torch.distributed.run rendezvous (RANK / MASTER_PORT missing)")
 
@@ -654,26 +440,29 @@ def worker_main(args):
         dist.all_reduce(t, op={"max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN, "sum": dist.ReduceOp.SUM}[op])
         return [float(x) for x in t]
 
+    def gather_bytes(mine):
+        """Everybody's bytes, indexed by rank."""
+        if link is not None:
+            return link.allgather(bytes(mine))
+        if dist is None:
+            return [bytes(mine)]
+        rows = [None] * world
+        dist.all_gather_object(rows, bytes(mine))   # this process' own bytes, between its own ranks (gloo rendezvous only)
+        return rows
+
     def new_unique_id():
         """rank 0 makes an RCCL unique id; the rendezvous carries its 128 bytes to the other ranks."""
         if args.dry_run:   # no GPU: /opt/rocm's ncclGetUniqueId needs one; the hand-over is what is rehearsed
-            raw = bytearray(range(nb.UNIQUE_ID_BYTES)) if rank == 0 else bytearray(nb.UNIQUE_ID_BYTES)
+            raw = bytes(range(nb.UNIQUE_ID_BYTES))
         else:
-            raw = bytearray(nb.comm_unique_id()) if rank == 0 else bytearray(nb.UNIQUE_ID_BYTES)
-        if link is not None:
-            raw = bytearray(link.broadcast(bytes(raw), src=0))
-        elif dist is not None:
-            buf = torch.frombuffer(raw, dtype=torch.uint8).clone()
-            dist.broadcast(buf, src=0)
-            raw = bytearray(buf.numpy().tobytes())
-        assert len(raw) == nb.UNIQUE_ID_BYTES and (not args.dry_run or bytes(raw) == bytes(range(nb.UNIQUE_ID_BYTES)))
-        return bytes(raw)
+            raw = nb.comm_unique_id() if rank == 0 else bytes(nb.UNIQUE_ID_BYTES)
+        raw = gather_bytes(raw)[0]
+        assert len(raw) == nb.UNIQUE_ID_BYTES
+        return raw
 
     def digests_agree(digest):
         """True when every rank's sha256 equals rank 0's."""
-        if link is not None:
-            return all(d == digest for d in link.allgather(bytes(digest)))
-        return _digests_agree(dist, torch, digest)
+        return all(d == bytes(digest) for d in gather_bytes(digest))
 
     current_leg = {"name": "headline"}
     host_gather = None
@@ -681,23 +470,10 @@ def worker_main(args):
     if sharded:
         def link_gather(rows, r, n):
             """In-place all-gather of host rows over the rendezvous (rows[r] is filled on entry)."""
-            if args.stall_leg and current_leg["name"] == args.stall_leg:
-                time.sleep(3600.0)   # rehearsal of a collective that never completes (--stall-leg)
-            if args.crash_leg and current_leg["name"] == args.crash_leg and r == 0:
-                os.abort()           # rehearsal of a leg that dies by the library's abort() convention (--crash-leg)
-            if link is not None:
-                for q, row in enumerate(link.allgather(rows[r].tobytes())):
-                    if q != r:
-                        rows[q] = np.frombuffer(row, dtype=rows.dtype)
-                return
-            if dist is None:
-                return
-            mine = torch.from_numpy(rows[r].copy())
-            parts = [torch.empty_like(mine) for _ in range(n)]
-            dist.all_gather(parts, mine)
-            for q in range(n):
+            notify("gather", leg=current_leg["name"], rank=r)
+            for q, row in enumerate(gather_bytes(rows[r].tobytes())):
                 if q != r:
-                    rows[q] = parts[q].numpy()
+                    rows[q] = np.frombuffer(row, dtype=rows.dtype)
 
     if args.transport in ("host", "direct") and sharded:
         host_gather = link_gather
@@ -709,9 +485,43 @@ def worker_main(args):
             return nb.SimPipeline(n_, m_, rank=rank, nranks=world, allgather=host_gather, direct=args.transport == "direct")
         return nb.SimPipeline(n_, m_, rank=rank, nranks=world, unique_id=new_unique_id())
 
+    # ---- preflight: what every attempt writes down BEFORE the first real contact between the ranks ----------------
+    flight = {"rank": rank, "transport": args.transport}
+
+    def say_flight(**fields):
+        """One `[preflight] {json}` line on stderr per stage, at once: a bring-up that dies later has left its trail with the
+        supervisor (nbody_amd/launch.py keeps the lines per attempt), and rank 0 puts every rank's record on the line."""
+        flight.update(fields)
+        print("[preflight] " + json.dumps(dict(fields, rank=rank, transport=args.transport)), file=sys.stderr, flush=True)
+
+    def preflight():
+        if args.dry_run:
+            say_flight(stage="device", dry_run=True)
+            return
+        visible, row = nb.preflight_peers()
+        say_flight(stage="device", pci=nb.device_info().split("pci=")[-1], device=local_rank % max(visible, 1), visible_devices=visible,
+                   can_access_peer=row, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
+        if world > 1 and args.transport != "host":     # the host transport needs no IPC: it must not depend on the probe either
+            say_flight(stage="ipc", entering="hipIpcGetMemHandle / hipIpcOpenMemHandle of the next rank's word")
+            rc, handle = nb.preflight_ipc_export(0x6e620000 + rank)
+            handles = gather_bytes(bytes([rc & 0xff]) + handle)
+            peer = (rank + 1) % world
+            if rc == 0 and handles[peer][0] == 0:
+                orc, ms = nb.preflight_ipc_open(handles[peer][1:], 0x6e620000 + peer)
+            else:
+                orc, ms = None, None
+            barrier()                                    # everybody has closed what it opened
+            nb.hip_lib().nb_hip_preflight_ipc_release()
+            say_flight(stage="ipc", ipc_export_rc=rc, ipc_export_error=None if rc == 0 else nb.hip_error_string(rc), ipc_open_peer=peer,
+                       ipc_open_rc=orc, ipc_open_error=None if not orc else nb.hip_error_string(orc), ipc_open_ms=ms)
+        if args.transport == "rccl":
+            say_flight(stage="rccl", entering="ncclCommInitRank + first all-gather (pipeline creation)")
+
     if not args.dry_run:
         ndev = nb.device_count()
         nb.hip_lib().nb_hip_set_device(local_rank if local_rank < max(ndev, 1) else local_rank % max(ndev, 1))
+    if sharded:
+        preflight()
     part, mass_len = make_workload(args.n, args.all_massive)
     n = part.shape[0]
 
@@ -743,8 +553,9 @@ def worker_main(args):
 
     def comm_evidence(sim):
         info = sim.comm_info()
-        lo = reduce([info["nranks"], info["rank"], info["device"]], "min")
-        hi = reduce([info["nranks"], info["rank"], info["device"]], "max")
+        up = sim.comm_bringup()
+        lo = reduce([info["nranks"], info["rank"], info["device"], up["small_gather_us"], up["comm_init_ms"]], "min")
+        hi = reduce([info["nranks"], info["rank"], info["device"], up["small_gather_us"], up["comm_init_ms"]], "max")
         sm = reduce([info["rank"], 1.0 if info["owns_comm"] else 0.0], "sum")
         return {
             "nranks_reported": {"min": int(lo[0]), "max": int(hi[0])},       # ncclCommCount on every rank
@@ -754,6 +565,10 @@ def worker_main(args):
             "version": info["rccl_version"],
             "lib": info["rccl_lib"],
             "first_gather_ms_rank0": info["first_gather_ms"],
+            # bring-up, measured at creation (nb_hip_comm_bringup): the warm 8-byte all-gather is the fixed cost of the per-step
+            # gather -- the number that replaces the 50 us ASSUMED in every S2 / S4 / S8 prediction
+            "comm_init_ms": {"min": lo[4], "max": hi[4]},
+            "small_gather_us": {"min": lo[3], "max": hi[3]},
         }
 
     # ---- the headline leg ---------------------------------------------------------------------------------------
@@ -762,7 +577,7 @@ def worker_main(args):
     sim = None
     if args.dry_run:
         uid = new_unique_id() if sharded else None
-        assert uid is None or len(uid) == nb.UNIQUE_ID_BYTES
+        assert uid is None or uid == bytes(range(nb.UNIQUE_ID_BYTES))
         plan = nb.shard_plan(n, mass_len, rank, world)
         assert plan["mass_count"] + plan["zero_count"] > 0 or n < world
         barrier()
@@ -773,12 +588,15 @@ def worker_main(args):
         shape, info = nb.plan_launch(plan["mass_count"] + plan["zero_count"], plan["src_padded"]), "dry-run"
         if sharded:
             extras["rccl"] = {"nranks_reported": {"min": None, "max": None}, "user_ranks": None, "devices": None,
-                              "ranks_with_communicator": 0, "version": None, "lib": None, "first_gather_ms_rank0": None}
+                              "ranks_with_communicator": 0, "version": None, "lib": None, "first_gather_ms_rank0": None,
+                              "comm_init_ms": None, "small_gather_us": None}
             zero = {"min": 0.0, "max": 0.0}
             extras["comm_ms_per_step"], extras["kernel_ms_per_step"] = dict(zero), dict(zero)
         runtime = None
     else:
         sim = make_sim(n, mass_len)
+        if sharded and args.transport == "rccl":
+            say_flight(stage="rccl", **{k: v for k, v in sim.comm_bringup().items() if k != "owns_comm"})
         if not sharded:
             sim.configure(graph=1)   # the K-step chain runs as a hipGraph on its first use, built inside the timed call
         sim.set_data(part)           # H2D + SoA split: outside the timed region
@@ -796,23 +614,11 @@ def worker_main(args):
             extras["rccl"] = comm_evidence(sim)
             d = sharded_detail(sim, args.steps)
             extras["comm_ms_per_step"], extras["kernel_ms_per_step"] = d["comm_ms_per_step"], d["kernel_ms_per_step"]
+    if sharded:
+        # every rank's bring-up record, on the line (the supervisor also holds the per-stage trail of attempts that died)
+        extras["preflight"] = [json.loads(b.decode()) for b in gather_bytes(json.dumps(flight).encode())]
 
     # ---- the JSON dict: complete from here on; later legs only add keys -----------------------------------------
-    out = {}
-    out_lock = threading.Lock()
-    emitted = {"done": False}
-
-    def emit(extra_keys=None):
-        """Write the one line (rank 0, once)."""
-        with out_lock:
-            if emitted["done"] or rank != 0:
-                return
-            emitted["done"] = True
-            line = dict(out)
-            if extra_keys:
-                line.update(extra_keys)
-            os.write(json_fd, (json.dumps(line) + "\n").encode())
-
     if rank == 0:
         interactions = float(n) * float(mass_len) * args.steps
         value = 0.0 if args.dry_run else interactions / elapsed
@@ -829,7 +635,11 @@ def worker_main(args):
             "peak": PEAK_FP32_VECTOR_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved_tflops / PEAK_FP32_VECTOR_TFLOPS,
+            # the same fraction from the wall clock of the K timed steps instead of the kernel's HIP events (= value x 14 /
+            # peak per GPU): the two differ by whatever a step spends outside its step kernels
+            "roofline_frac_from_wall": value * FLOP_PER_INTERACTION / (PEAK_FP32_VECTOR_TFLOPS * 1e12 * world),
             "traffic": traffic,
+            "traffic_measured_in_this_run": False,   # PMC passes cannot run inside the timed process: looked up, see traffic_note
             "traffic_note": traffic_note,
             "traffic_parts": None if unmeasured else pmc_traffic_parts(n, shape, passes),
             "traffic_algorithmic": algorithmic_bytes_per_launch(n, mass_len, passes) if world == 1 else None,
@@ -865,7 +675,7 @@ def worker_main(args):
                                 f"dt={DT}; {n * mass_len:.4g} interactions/step; one PerformSimUpdate({args.steps}) call",
                     "parallelism": (f"receivers sharded N/{world} per GPU, all-gather of source positions per step"
                                     + (" by direct device-to-device pushes (no RCCL)" if args.transport == "direct" else
-                                       " over the caller-supplied HOST transport (rehearsal, not RCCL)" if host_gather else ""))
+                                       " staged through the host over the rendezvous link (no RCCL, no IPC)" if host_gather else ""))
                                    if world > 1 else "single GPU",
                     "kernel": shape,
                     "device": info,
@@ -885,54 +695,98 @@ def worker_main(args):
             if cpu is not None:
                 out["cpu_baseline"] = cpu
 
-    def put(key, val):
-        if rank == 0:
-            with out_lock:
-                out[key] = val
-
     # Single GPU: from here on every further leg -- clock probe, parity stamp, repeats, the clock-sampler leg, the LDS
     # route, extra_configs -- runs with the line in hand: the library's error convention is abort(), and a fatal signal
     # inside any of them still writes the headline (plus "extras_aborted": which leg) through the C-level handler.
     solo_gasp = LastGasp(json_fd) if (rank == 0 and not sharded and not args.dry_run) else None
+    skipped_legs = []
 
-    def solo_leg(name):
+    def solo_leg(name, need_s=0.0):
+        """Arms the last-gasp line for the leg and says whether the budget still holds it (need_s: what the leg takes)."""
+        if time_left() < need_s:
+            skipped_legs.append(name)
+            put("legs_skipped_for_budget", list(skipped_legs))
+            return False
         if solo_gasp:
             with out_lock:
                 solo_gasp.arm((json.dumps(dict(out, extras_aborted=f"{name} (fatal signal)")) + "\n").encode())
-            if args.crash_leg == name:
-                os.abort()   # rehearsal of a leg that dies by the library's abort() convention (--crash-leg)
+        notify("leg", leg=name, rank=rank, solo=True)
+        return True
 
     if not sharded and not args.dry_run and rank == 0:
-        if not args.no_clock_probe:
+        if not args.no_clock_probe and solo_leg("clock probe", 2.0):
             # the clock the chip holds for the interaction statement alone, asked right after the timed steps and outside
             # them: a separate probe kernel (include/nbody_hip.h nb_hip_probe_clock); the product kernels carry no stamps
-            solo_leg("clock probe")
             try:
                 clock = nb.probe_clock(40.0)
             except Exception as e:  # pragma: no cover - diagnostic only
                 clock = {"error": str(e)}
             with out_lock:
                 out["roofline"].update(held_clock_fields(clock, None, per_launch_s, launch_interactions, info, achieved_tflops))
-        if not args.no_parity:
-            solo_leg("parity stamp")
+        if not args.no_parity and solo_leg("parity stamp", 10.0):
             put("parity", parity_stamp(sim, mass_len))   # after the timed call, outside it
 
     # ---- optional legs ------------------------------------------------------------------------------------------
     if sharded:
-        guard = LegGuard(rank, lambda leg: emit({"extras_aborted": leg}), args.leg_deadline_s) if not args.dry_run else None
         gasp = LastGasp(json_fd) if (rank == 0 and not args.dry_run) else None
 
-        def leg(name):
+        def leg(name, need_s=0.0):
+            """Arms the deadline and the last-gasp line for the leg; False (on every rank alike) when the budget no longer
+            holds what the leg needs -- it is then listed under legs_skipped_for_budget instead of being started."""
+            if need_s and reduce([time_left()], "min")[0] < need_s + 5.0:
+                skipped_legs.append(name)
+                put("legs_skipped_for_budget", list(skipped_legs))
+                return False
             current_leg["name"] = name
             if guard:
                 guard.arm(name)
             if gasp:
                 with out_lock:
                     gasp.arm((json.dumps(dict(out, extras_aborted=f"{name} (fatal signal)")) + "\n").encode())
+            return True
 
+        def done_with_legs():
+            if guard:
+                guard.disarm()
+            if gasp:
+                gasp.disarm()
+
+        single_gpu_state = {}
+
+        def self_check(pipeline, steps_run):
+            """NOT optional for any N > 1 headline (--no-extras keeps it): every rank must hold the same full state, and it
+            must be the single-GPU state of the same steps -- the check that would catch a stale or torn exchange."""
+            if args.dry_run:
+                check = {"ranks_agree": digests_agree(hashlib.sha256(part.tobytes()).digest()), "vs_single_gpu_rel_l2_pos": None}
+                notify("self_check", check=check, transport=args.transport)
+                return check
+            got = pipeline.get_data()  # collective
+            check = {"ranks_agree": digests_agree(hashlib.sha256(got.tobytes()).digest()), "steps": steps_run}
+            notify("self_check", check=check, transport=args.transport)
+            if rank == 0:
+                if steps_run not in single_gpu_state:
+                    one = nb.SimPipeline(n, mass_len)
+                    one.set_data(part)
+                    one.update(steps_run, DT)
+                    single_gpu_state[steps_run] = one.get_data()
+                    one.close()
+                want = single_gpu_state[steps_run]
+                dp = (got[:, 0:2].astype(np.float64) - want[:, 0:2]).ravel()
+                check["vs_single_gpu_rel_l2_pos"] = float(np.sqrt(dp @ dp) / np.linalg.norm(want[:, 0:2].astype(np.float64)))
+                check["vs_single_gpu_max_abs_pos"] = float(np.abs(dp).max())
+                check["static_fields_equal"] = bool(np.array_equal(got[:, 6:8], want[:, 6:8]))
+                # the sharded sum differs from the single-GPU one only in the order M terms are added (1e-4: DESIGN.md section 5)
+                check["ok"] = bool(check["ranks_agree"] and check["static_fields_equal"] and check["vs_single_gpu_rel_l2_pos"] <= 1e-4)
+            # which physical devices took part: PCI addresses (ordinals can all read 0 when every rank sees one GPU)
+            seen = sorted(set(gather_bytes(nb.device_info().split("pci=")[-1].encode())))
+            check["devices"] = [d.decode() for d in seen]
+            check["crossed_devices"] = len(seen) > 1
+            barrier()
+            return check
+
+        leg("self_check")
+        put("self_check", self_check(sim, steps_done))
         if args.dry_run:
-            digest = hashlib.sha256(part.tobytes()).digest()
-            put("self_check", {"ranks_agree": digests_agree(digest), "vs_single_gpu_rel_l2_pos": None})
             part5, m5 = make_workload(args.n5)
             _ = new_unique_id()
             p5 = nb.shard_plan(part5.shape[0], m5, rank, world)
@@ -944,70 +798,36 @@ def worker_main(args):
             ] + ([dict(_extra_entry(n, mass_len, 0, 0, args.steps, 0.0, None, world), transport="direct (dry run)")]
                  if host_gather is None else [])
               + [_extra_entry(n, mass_len, 0, 1, args.steps, 0.0, None, world)])
+        elif args.no_extras:
+            done_with_legs()
+            sim.close()
+            sim = None
         else:
-            # NOT optional for any N > 1 headline (--no-extras keeps it): every rank must hold the same full state, and it must
-            # be the single-GPU state of the same steps -- the check that would catch a stale or torn exchange
-            single_gpu_state = {}
-
-            def self_check(pipeline, steps_run):
-                got = pipeline.get_data()  # collective
-                check = {"ranks_agree": digests_agree(hashlib.sha256(got.tobytes()).digest()), "steps": steps_run}
-                if rank == 0:
-                    if steps_run not in single_gpu_state:
-                        one = nb.SimPipeline(n, mass_len)
-                        one.set_data(part)
-                        one.update(steps_run, DT)
-                        single_gpu_state[steps_run] = one.get_data()
-                        one.close()
-                    want = single_gpu_state[steps_run]
-                    dp = (got[:, 0:2].astype(np.float64) - want[:, 0:2]).ravel()
-                    check["vs_single_gpu_rel_l2_pos"] = float(np.sqrt(dp @ dp) / np.linalg.norm(want[:, 0:2].astype(np.float64)))
-                    check["vs_single_gpu_max_abs_pos"] = float(np.abs(dp).max())
-                    check["static_fields_equal"] = bool(np.array_equal(got[:, 6:8], want[:, 6:8]))
-                    # the sharded sum differs from the single-GPU one only in the order M terms are added (1e-4: DESIGN.md section 5)
-                    check["ok"] = bool(check["ranks_agree"] and check["static_fields_equal"] and check["vs_single_gpu_rel_l2_pos"] <= 1e-4)
-                # which physical devices took part: PCI addresses (ordinals can all read 0 when every rank sees one GPU)
-                pci = nb.device_info().split("pci=")[-1].encode()
-                seen = sorted(set(link.allgather(pci))) if link is not None else [pci]
-                check["devices"] = [d.decode() for d in seen]
-                check["crossed_devices"] = len(seen) > 1
-                barrier()
-                return check
-
-            leg("self_check")
-            put("self_check", self_check(sim, steps_done))
-            if args.no_extras:
-                if guard:
-                    guard.disarm()
-                if gasp:
-                    gasp.disarm()
-                sim.close()
-                sim = None
-        if not args.dry_run and not args.no_extras:
             extra = []
             put("extra_configs", extra)   # the list grows in place: a deadline line carries the legs that finished
+            step_s = elapsed / args.steps
             # the overlapped step on the same pipeline
-            leg("overlap")
-            sim.configure(overlap=1)
-            e1 = timed_leg(sim, args.steps, 1)
-            extra.append(_extra_entry(n, mass_len, 1, 0, args.steps, e1, sharded_detail(sim, args.steps), world))
-            sim.configure(overlap=0)
+            if leg("overlap", 2 * (args.steps + 1) * step_s):
+                sim.configure(overlap=1)
+                e1 = timed_leg(sim, args.steps, 1)
+                extra.append(_extra_entry(n, mass_len, 1, 0, args.steps, e1, sharded_detail(sim, args.steps), world))
+                sim.configure(overlap=0)
             # BASELINE.json config 5: N = 2^22, plain and overlapped (own communicator: a second ncclCommInitRank)
-            leg("config5")
-            part5, m5 = make_workload(args.n5)
-            sim5 = make_sim(part5.shape[0], m5)
-            sim5.set_data(part5)
-            for ov in (0, 1):
-                leg("config5")
-                sim5.configure(overlap=ov)
-                e5 = timed_leg(sim5, 3, 1)
-                extra.append(_extra_entry(part5.shape[0], m5, ov, 0, 3, e5, sharded_detail(sim5, 3), world))
-            sim5.close()
+            scale5 = (args.n5 / float(n)) ** 2
+            if leg("config5", 20.0 + 2 * 8 * step_s * scale5):
+                part5, m5 = make_workload(args.n5)
+                sim5 = make_sim(part5.shape[0], m5)
+                sim5.set_data(part5)
+                for ov in (0, 1):
+                    leg("config5")
+                    sim5.configure(overlap=ov)
+                    e5 = timed_leg(sim5, 3, 1)
+                    extra.append(_extra_entry(part5.shape[0], m5, ov, 0, 3, e5, sharded_detail(sim5, 3), world))
+                sim5.close()
             # the direct exchange (no RCCL; slices pushed device-to-device into IPC-mapped peers,
             # one barrier per step over the rendezvous link) on the headline workload, for an RCCL-vs-direct comparison
             # from the same command -- only when the run's own transport is RCCL (otherwise the legs above were it)
-            if host_gather is None and link_gather is not None:
-                leg("direct")
+            if host_gather is None and link_gather is not None and leg("direct", 10.0 + 3 * (args.steps + 1) * step_s * world):
                 simd = nb.SimPipeline(n, mass_len, rank=rank, nranks=world, allgather=link_gather, direct=True)
                 simd.set_data(part)
                 ed = timed_leg(simd, args.steps, 1)
@@ -1024,34 +844,28 @@ def worker_main(args):
             # LAST, because it is the least-travelled path of the stack and a stall here must not cost the legs above:
             # north star: "multi-step chains are captured as hipGraph" -- the {kernel, all-gather} x K chain captured
             # from the stream and replayed (RCCL inside stream capture; a host callback cannot be captured)
-            leg("sharded_graph")
-            if host_gather is None:
+            if host_gather is not None:
+                extra.append(dict(_extra_entry(n, mass_len, 0, 1, args.steps, 0.0, None, world),
+                                  skipped="host / direct transport: a host callback cannot run inside a captured graph"))
+            elif leg("sharded_graph", 10.0 + 3 * args.steps * step_s):
                 sim.configure(sharded_graph=1)
                 eg = timed_leg(sim, args.steps, args.steps)   # the warm-up call captures and instantiates the chain
                 entry = _extra_entry(n, mass_len, 0, 1, args.steps, eg, None, world)
                 entry["graph_stats"] = sim.graph_stats()
                 extra.append(entry)
                 sim.configure(sharded_graph=0)
-            else:
-                if args.stall_leg == "sharded_graph":
-                    sim.update(1, DT)
-                extra.append(dict(_extra_entry(n, mass_len, 0, 1, args.steps, 0.0, None, world),
-                                  skipped="host transport: a host callback cannot run inside a captured graph"))
             sim.close()
             sim = None
-            if guard:
-                guard.disarm()
-            if gasp:
-                gasp.disarm()
+            done_with_legs()
     elif not sharded and not args.no_extras and not args.dry_run:
         # same K steps twice more (run-to-run spread), then the LDS-tile route of the north star on the same chain
-        solo_leg("repeats")
-        put("repeat_ms_per_step", [timed_leg(sim, args.steps, 0) / args.steps * 1e3 for _ in range(2)])
-        if not args.no_clock_probe and rank == 0:
+        if solo_leg("repeats", 3 * elapsed):
+            put("repeat_ms_per_step", [timed_leg(sim, args.steps, 0) / args.steps * 1e3 for _ in range(2)])
+        if not args.no_clock_probe and rank == 0 and solo_leg("clock sampler leg", 2 * elapsed + 2.0):
             # the clock the chip holds UNDER THE STEP KERNEL: the same K steps once more with the sampler running beside them
-            solo_leg("clock sampler leg")
             try:
-                nb.clock_sampler_begin(0.5, 3.0 * elapsed * 1e3 + 500.0)
+                # the sampler's own bound (the library clamps to it too): a leg longer than that is sampled over its first 20 s
+                nb.clock_sampler_begin(0.5, min(nb.CLOCK_SAMPLER_MAX_MS, 3.0 * elapsed * 1e3 + 500.0))
                 e_clk = timed_leg(sim, args.steps, 0)
                 clk_ms, clk_launches = sim.last_step_ms()
                 sampled = nb.clock_sampler_end()
@@ -1059,17 +873,18 @@ def worker_main(args):
                 sampled["leg"] = {"ms_per_step": e_clk / args.steps * 1e3, "kernel_ms_per_launch": clk_s * 1e3,
                                   "cycles_per_wave_interaction": clk_s * sampled["clock_ghz"] * 1e9 * 4 * device_cus(info)
                                   / (launch_interactions / 64.0) if sampled.get("clock_ghz") else None}
+                if e_clk * 1e3 > nb.CLOCK_SAMPLER_MAX_MS:
+                    sampled["note"] = f"the leg took {e_clk:.1f} s: sampled over its first {nb.CLOCK_SAMPLER_MAX_MS / 1e3:g} s only"
                 with out_lock:
                     out["roofline"].update(held_clock_fields(clock, sampled, per_launch_s, launch_interactions, info, achieved_tflops))
             except Exception as e:  # pragma: no cover - diagnostic only
                 put("clock_sampler_error", str(e))
-        solo_leg("alt_lds")
-        sim.configure(variant=0)
-        e_lds = timed_leg(sim, args.steps, 2)
-        lds_ms, lds_launches = sim.last_step_ms()
-        lds_s = lds_ms * 1e-3 / max(lds_launches, 1)
-        lds_tf = float(n) * float(mass_len) * (args.steps / max(lds_launches, 1)) * FLOP_PER_INTERACTION / lds_s / 1e12
-        if rank == 0:
+        if solo_leg("alt_lds", 2 * elapsed + 2.0):
+            sim.configure(variant=0)
+            e_lds = timed_leg(sim, args.steps, 2)
+            lds_ms, lds_launches = sim.last_step_ms()
+            lds_s = lds_ms * 1e-3 / max(lds_launches, 1)
+            lds_tf = float(n) * float(mass_len) * (args.steps / max(lds_launches, 1)) * FLOP_PER_INTERACTION / lds_s / 1e12
             with out_lock:
                 out["roofline"]["alt_lds"] = {
                     "note": "same K steps through the LDS-tile source route (north star's design; variant=0), bit-identical "
@@ -1080,18 +895,21 @@ def worker_main(args):
         sim.close()
         sim = None
         if not args.all_massive and args.n == N_PARTICLES and not args.no_extra_configs:
-            solo_leg("extra_configs C2/C3/N2/C1")
-            configs = single_gpu_configs(nb, stamp=not args.no_parity)
+            configs = []
             put("extra_configs", configs)
-            solo_leg("extra_configs S2/S4/S8/C5S8")
-            try:
-                configs.extend(shard_scaling_configs(nb, elapsed / args.steps * 1e3, stamp=not args.no_parity, n5=args.n5))
-            except Exception as e:  # pragma: no cover - diagnostic only
-                configs.append({"config": "S2/S4/S8/C5S8", "error": str(e)})
+            if solo_leg("extra_configs C2/C3/N2/C1", 30.0):
+                configs.extend(single_gpu_configs(nb, stamp=not args.no_parity))
+            if solo_leg("extra_configs S2/S4/S8/C5S8", 40.0):
+                try:
+                    configs.extend(shard_scaling_configs(nb, elapsed / args.steps * 1e3, stamp=not args.no_parity, n5=args.n5))
+                except Exception as e:  # pragma: no cover - diagnostic only
+                    configs.append({"config": "S2/S4/S8/C5S8", "error": str(e)})
     if sim is not None:
         sim.close()
     if solo_gasp:
         solo_gasp.disarm()
+    if guard:
+        guard.disarm()
 
     emit()
 
@@ -1207,18 +1025,6 @@ def single_gpu_configs(nb, stamp=True):
     return out
 
 
-XGMI_LINK_GBS = 153.0            # per direction and link, 7 links per GPU (task brief)
-GATHER_LATENCY_ASSUMED_MS = 0.05  # fixed cost of one small in-stream all-gather: an ASSUMPTION, never measured on > 1 device here
-
-
-def gather_estimate_ms(mass_chunk, ranks):
-    """What one per-step all-gather of `mass_chunk` float2 per rank should cost across `ranks` GPUs: every slice rides its
-    own xGMI link (direct all-gather), plus an assumed fixed latency.  An estimate with its source stated --
-    the only multi-GPU term of the curve that a single-GPU box cannot measure."""
-    wire = mass_chunk * 8.0 / (XGMI_LINK_GBS * 1e9) * 1e3 if ranks > 1 else 0.0
-    return wire + (GATHER_LATENCY_ASSUMED_MS if ranks > 1 else 0.0)
-
-
 def shard_leg(nb, name, part, m, ranks, steps, t1_ms=None, stamp=True):
     """One rank's share of a sharded step, timed on ONE GPU: all `ranks` shards of the world live in this process
     (nb_hip_local_group_*: the same shard plan, kernels, launch shape and mirror / gather layout as the RCCL path, the
@@ -1282,18 +1088,6 @@ def shard_scaling_configs(nb, t1_ms, stamp=True, n5=N_CONFIG5):
     return out
 
 
-def _digests_agree(dist, torch, digest):
-    """True when every rank's sha256 equals rank 0's."""
-    if dist is None:
-        return True
-    mine = torch.frombuffer(bytearray(digest), dtype=torch.uint8).clone()
-    ref = mine.clone()
-    dist.broadcast(ref, src=0)
-    same = torch.tensor([1.0 if bool((mine == ref).all()) else 0.0], dtype=torch.float64)
-    dist.all_reduce(same, op=dist.ReduceOp.MIN)
-    return bool(same.item() == 1.0)
-
-
 def _extra_entry(n, m, overlap, sharded_graph, steps, elapsed, detail, world):
     e = {
         "workload": f"srand(11037) MakeGalaxies({n}, 2), N={n}, mass_len={m}, dt={DT}, N/{world} receivers per GPU",
@@ -1313,244 +1107,18 @@ def _extra_entry(n, m, overlap, sharded_graph, steps, elapsed, detail, world):
     return e
 
 
-# ---- N > 1: a GPU-free supervisor over fresh rank processes --------------------------------------------------------------
-
-RUNNING = -1000   # status of a rank process that has not ended yet (exit codes and -signal numbers are > -1000)
-
-
-def _die_with_parent():
-    """In the child, between fork and exec: a rank never outlives the supervisor that started it, however that one ends
-    (PR_SET_PDEATHSIG survives the exec; the signal handlers of supervise() cover the polite ways of being stopped)."""
-    try:
-        C.CDLL(None).prctl(1, 9)   # PR_SET_PDEATHSIG, SIGKILL
-    except Exception:
-        pass
-
-
-class RankProcess:
-    """One worker (this file, NB_BENCH_WORKER=1) for one rank of one attempt, started by a process that never touches the
-    GPU.  Rank 0's stdout (the JSON line) is captured; every worker's stderr is forwarded as it comes and its tail kept."""
-
-    def __init__(self, argv, env, rank, capture_stdout):
-        self.rank = rank
-        self.lines, self.tail = [], []
-        self.proc = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, preexec_fn=_die_with_parent,
-                                     stdout=subprocess.PIPE if capture_stdout else sys.stderr.fileno(), stderr=subprocess.PIPE)
-        self.threads = [threading.Thread(target=self._pump_err, daemon=True)]
-        if capture_stdout:
-            self.threads.append(threading.Thread(target=self._pump_out, daemon=True))
-        for t in self.threads:
-            t.start()
-
-    def _pump_out(self):
-        for raw in self.proc.stdout:
-            self.lines.append(raw.decode(errors="replace"))
-
-    def _pump_err(self):
-        for raw in self.proc.stderr:
-            text = raw.decode(errors="replace")
-            sys.stderr.write(text)
-            sys.stderr.flush()
-            self.tail.append(text)
-            del self.tail[:-40]
-
-    def status(self):
-        rc = self.proc.poll()
-        return RUNNING if rc is None else rc
-
-    def end(self):
-        """By exact pid: this Popen's own child, nothing matched by name."""
-        if self.proc.poll() is None:
-            self.proc.kill()
-
-    def finish(self):
-        self.proc.wait()
-        for t in self.threads:
-            t.join(5.0)
-
-
-def _free_port():
-    import socket
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
-def _headline_of(lines, world, dry_run):
-    """(line dict or None, why not): the last JSON object rank 0 wrote, accepted when it is a complete headline -- metric and
-    value present and, for a real multi-rank run, a self-check that passed."""
-    for text in reversed(lines):
-        text = text.strip()
-        if not text.startswith("{"):
-            continue
-        try:
-            line = json.loads(text)
-        except ValueError:
-            continue
-        if "metric" not in line or "value" not in line:
-            return None, "rank 0 wrote a line without metric / value"
-        if world > 1 and not dry_run:
-            check = line.get("self_check")
-            if not check:
-                return None, "the line carries no self_check"
-            if not check.get("ranks_agree") or check.get("ok") is False:
-                return line, "self_check failed: " + json.dumps(check)
-        return line, None
-    return None, "rank 0 wrote no JSON line"
-
-
-class Supervisor:
-    """`bench.py --gpus N` (N > 1) started bare, or started once per rank by torch.distributed.run: THIS process never makes
-    a GPU call.  Bare: it starts N fresh rank processes itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT in their
-    environment) -- the shape of the reference harness, one plain command (src/bench.c:41-74).  Under torch.distributed.run:
-    every rank process supervises ONE fresh worker and the supervisors keep each other informed over their own rank link.
-    Either way an attempt whose ranks do not all deliver -- RCCL that does not come up (the library's watchdog leaves with 3,
-    its error convention with abort()), a self-check that fails -- is followed, with --transport auto, by a SECOND attempt in
-    fresh processes over the direct exchange; the line then carries "transport_fallback".  Nothing is ever retried or
-    re-executed inside a process that has touched the GPU; stragglers are ended by exact pid, and no rank outlives the
-    supervisor that started it.
-    Exit code: what the ranks of the LAST attempt left with -- 0 only when every one of them did; a run whose optional leg
-    stalled (4) or aborted (6) after the headline still writes the complete line ("extras_aborted",
-    launch.attempts[].child_rcs) and still does not report success."""
-
-    GRACE_S = 20.0   # what the other ranks get once one has left with an error (rank 0 may be writing its line)
-
-    def __init__(self, args, argv):
-        self.args = args
-        under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ
-        if under_launcher:
-            self.rank, self.world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-            self.local = [(self.rank, int(os.environ.get("LOCAL_RANK", self.rank)))]
-            self.port = os.environ["MASTER_PORT"]
-            self.mode = "torch.distributed.run: every rank process stays GPU-free and supervises one fresh worker"
-        else:
-            self.rank, self.world = 0, args.gpus
-            self.local = [(r, r) for r in range(self.world)]
-            self.port = str(_free_port())
-            self.mode = f"bare: bench.py started its {self.world} rank processes itself"
-        self.run_id = os.environ.get("TORCHELASTIC_RUN_ID", "none")
-        self.link = None
-        if under_launcher and self.world > 1:
-            from nbody_amd.ranklink import RankLink
-            self.link = RankLink(self.rank, self.world, name=f"nbody_sup_{self.port}_{self.run_id}")
-        # what the workers get: the same command line minus what the supervisor decides
-        self.passthrough, skip = [], False
-        for a in argv:
-            if skip:
-                skip = False
-            elif a == "--transport":
-                skip = True
-            elif not a.startswith("--transport="):
-                self.passthrough.append(a)
-        self.transports = ["rccl", "direct"] if args.transport == "auto" else [args.transport]
-        self.ranks, self.attempts = [], []
-
-    def everyone(self, values):
-        """Status of every rank, indexed by rank (bare: they are all mine)."""
-        if self.link is None:
-            return list(values)
-        return [int(x) for row in self.link.allgather([float(v) for v in values]) for x in row]
-
-    def end_my_ranks(self):
-        """Whatever ends this supervisor early -- a launcher's SIGTERM, an exception on the supervisors' link -- must not
-        leave rank processes behind on the GPUs: end exactly the children this process started."""
-        for p in self.ranks:
-            p.end()
-
-    def attempt(self, index, transport):
-        """One set of fresh rank processes over `transport`: (line or None, why it does not count or None, record)."""
-        env = dict(os.environ, NB_BENCH_WORKER="1", WORLD_SIZE=str(self.world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(self.port),
-                   NB_BENCH_ATTEMPT=str(index), TORCHELASTIC_RUN_ID=self.run_id)
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if len(self.transports) > 1 and index == 0:
-            env.setdefault("NB_HIP_COMM_TIMEOUT_S", "75")   # there is a fallback: do not sit out the library's 180 s
-        t0 = time.monotonic()
-        self.ranks[:] = [RankProcess(self.passthrough + ["--transport", transport], dict(env, RANK=str(r), LOCAL_RANK=str(lr)), r, r == 0)
-                         for r, lr in self.local]
-        first_failure = None
-        while True:
-            seen = self.everyone([p.status() for p in self.ranks])
-            if all(v != RUNNING for v in seen):
-                break
-            now = time.monotonic()
-            if first_failure is None and any(v not in (RUNNING, 0) for v in seen):
-                first_failure = now
-            # a rank that left with an error takes the attempt with it: the others get a moment (rank 0 may be writing
-            # its line; the library's own watchdogs may still fire), then go -- by exact pid
-            if (first_failure is not None and now - first_failure > self.GRACE_S) or now - t0 > self.args.attempt_timeout_s:
-                self.end_my_ranks()
-            time.sleep(0.25)
-        for p in self.ranks:
-            p.finish()
-        rcs = self.everyone([p.status() for p in self.ranks])
-        record = {"transport": transport, "child_rcs": rcs, "seconds": round(time.monotonic() - t0, 2)}
-        # every rank's last words, indexed by rank (under a launcher each supervisor holds one worker's)
-        tails = ["".join(p.tail)[-900:] for p in self.ranks]
-        if self.link is not None:
-            tails = [t.decode(errors="replace") for t in self.link.allgather(tails[0].encode())]
-        line, why = None, None
-        if self.rank == 0:
-            line, why = _headline_of(self.ranks[0].lines, self.world, self.args.dry_run)
-            if line is None or why is not None:
-                # whose stderr explains it: a rank that left with something other than Python's generic 1, if there is one
-                bad = sorted(range(self.world), key=lambda r: (rcs[r] == 0, rcs[r] == 1))[0]
-                record["why_not"] = why
-                record["stderr_tail"] = f"[rank {bad}, rc {rcs[bad]}] " + tails[bad]
-        good = 1 if (line is not None and why is None) else 0
-        if self.link is not None:
-            good = int(self.link.broadcast(good if self.rank == 0 else None, src=0))
-        self.attempts.append(record)
-        return line, why, bool(good)
-
-    def run(self):
-        line, why, good = None, "no attempt ran", False
-        for index, transport in enumerate(self.transports):
-            line, why, good = self.attempt(index, transport)
-            if good:
-                break
-        if self.link is not None:
-            self.link.barrier()
-            self.link.close()
-        last = [rc for rc in self.attempts[-1]["child_rcs"] if rc not in (0, RUNNING)]
-        code = (min(abs(last[0]), 255) or 1) if last else 0      # the worst the final attempt's ranks left with; 0 only when all did
-        if self.rank != 0:
-            return code if good else (code or 1)
-        launch = {"mode": self.mode, "attempts": self.attempts}
-        if good:
-            line["launch"] = launch
-            if len(self.attempts) > 1:
-                first = self.attempts[0]
-                line["transport_fallback"] = {"from": first["transport"], "to": self.attempts[-1]["transport"], "rc": first["child_rcs"],
-                                              "why": first.get("why_not"), "stderr_tail": first.get("stderr_tail", "")[-600:]}
-            print(json.dumps(line), flush=True)
-            return code
-        # no complete headline from any attempt: still one line, saying so
-        partial = line if isinstance(line, dict) else {}
-        partial.update({"metric": partial.get("metric", "particle-pair interactions/sec at N=2^20"), "value": partial.get("value"),
-                        "unit": "interactions/s", "n_gpus": self.world, "error": why, "launch": launch})
-        print(json.dumps(partial), flush=True)
-        return code or 1
-
-
-def supervise(args, argv):
-    import signal
-    sup = Supervisor(args, argv)
-    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
-        signal.signal(sig, lambda n, f: (sup.end_my_ranks(), os._exit(128 + n)))
-    try:
-        return sup.run()
-    finally:
-        sup.end_my_ranks()
-
-
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if os.environ.get("NB_BENCH_WORKER") == "1" or (args.gpus <= 1 and not launched):
+        if os.environ.get("NB_BENCH_REHEARSE"):     # failure rehearsals live with the tests, not here (tests/bench_rehearsal.py)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import bench_rehearsal
+            bench_rehearsal.install(sys.modules[__name__])
         worker_main(args)     # one rank; the only place a GPU is touched
         return 0
-    return supervise(args, argv)
+    return supervise(args, argv, os.path.abspath(__file__))   # GPU-free: nbody_amd/launch.py
 
 
 if __name__ == "__main__":

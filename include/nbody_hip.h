@@ -125,6 +125,34 @@ uint32_t nb_hip_last_step_breakdown(SimPipeline *sim, double *kernel_ms, double 
 int nb_hip_comm_info(const SimPipeline *sim, int *nranks, int *rank, int *device, int *rccl_version,
                      double *first_gather_ms, char *lib_path, uint32_t len);
 
+/*
+ * Bring-up timings of the pipeline's RCCL communicator, taken once at creation: host milliseconds of ncclCommInitRank,
+ * device milliseconds of the first (256-byte-per-rank, verified) all-gather including RCCL's lazy channel set-up, and
+ * device microseconds of ONE warm 8-byte-per-rank all-gather (mean of 16 issued back to back in-stream): the fixed cost
+ * of the per-step gather.  Returns 1 when the pipeline owns a communicator, else 0 (all three read 0 then).
+ */
+int nb_hip_comm_bringup(const SimPipeline *sim, double *init_ms, double *first_gather_ms, double *small_gather_us);
+
+/*
+ * Preflight probes for multi-GPU harnesses (bench.py, nbody-bench): asked BEFORE the first real contact between ranks, so
+ * that a failed bring-up can say why.  Unlike the rest of this ABI they REPORT instead of aborting (they still abort when
+ * this process has no gfx950 device at all).
+ *   nb_hip_preflight_peers       row[q] = hipDeviceCanAccessPeer(this process' device, q): 1 / 0, 1 for the device itself,
+ *                                -1 when the query failed, -2 for q >= the visible device count (returned)
+ *   nb_hip_preflight_ipc_export  allocates one 4 KiB device word holding `tag` and writes its hipIpcMemHandle_t (64 bytes)
+ *                                to handle64; returns the hipError_t (0 = ok)
+ *   nb_hip_preflight_ipc_open    maps a PEER's exported handle (hipIpcOpenMemHandle, lazy peer access), reads the word,
+ *                                unmaps; returns 0 when the word is expect_tag, the hipError_t of the failing call, or -1
+ *                                when the word read is not the peer's; *ms = host milliseconds of open + read + close
+ *   nb_hip_preflight_ipc_release frees the exported word (call after every peer has finished its open)
+ *   nb_hip_error_string          text of a code returned by the two calls above
+ */
+int nb_hip_preflight_peers(int *row, int len);
+int nb_hip_preflight_ipc_export(void *handle64, uint32_t tag);
+int nb_hip_preflight_ipc_open(const void *handle64, uint32_t expect_tag, double *ms);
+void nb_hip_preflight_ipc_release(void);
+const char *nb_hip_error_string(int hip_error);
+
 /* Cached hipGraph chains of this pipeline (at most 8, least recently used evicted); *dt_uploads = times a new step
  * size was written to device memory (the kernels read dt from there, like the reference's uniform block,
  * sim_gpu.c:268-284, so a changed dt never rebuilds or patches a cached chain). */
@@ -158,6 +186,7 @@ int nb_hip_probe_clock(double target_ms, double *clock_ghz, double *clock_ghz_mi
  * bench.py brackets a repeat of the headline leg with it (roofline.held_clock_ghz): the probe above loads the chip with a
  * denser loop than the step kernel's and therefore reads a lower clock than the step kernel holds.
  */
+#define NB_CLOCK_SAMPLER_MAX_MS 20000.0 /* period_ms below 0.05 and max_ms above this are clamped, never refused */
 int nb_hip_clock_sampler_begin(double period_ms, double max_ms);
 int nb_hip_clock_sampler_end(double *clock_ghz, double *clock_ghz_min, double *clock_ghz_max, double *per_xcd_ghz8,
                              double *profile10, double *span_ms, uint32_t *dropped_intervals);

@@ -31,6 +31,7 @@ def _nb_g_from_header():
 
 NB_G = _nb_g_from_header()
 UNIQUE_ID_BYTES = 128
+CLOCK_SAMPLER_MAX_MS = 20000.0   # include/nbody_hip.h NB_CLOCK_SAMPLER_MAX_MS: larger bounds are clamped by the library
 
 
 class WorldData(C.Structure):
@@ -63,6 +64,12 @@ HIP_API = {
     "nb_hip_last_step_breakdown": (C.c_uint32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "nb_hip_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_char_p, C.c_uint32]),
+    "nb_hip_comm_bringup": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "nb_hip_preflight_peers": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    "nb_hip_preflight_ipc_export": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "nb_hip_preflight_ipc_open": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]),
+    "nb_hip_preflight_ipc_release": (None, []),
+    "nb_hip_error_string": (C.c_char_p, [C.c_int]),
     "nb_hip_graph_stats": (C.c_uint32, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "nb_hip_runtime_version": (C.c_int, []),
     "nb_hip_probe_clock": (C.c_int, [C.c_double] + [C.POINTER(C.c_double)] * 5),
@@ -196,6 +203,32 @@ def clock_sampler_end():
             "profile_ghz": [float(v) for v in profile], "span_ms": span.value, "intervals": int(n), "dropped_intervals": int(dropped.value)}
 
 
+def preflight_peers(max_devices=16):
+    """include/nbody_hip.h nb_hip_preflight_peers: (visible devices, hipDeviceCanAccessPeer row of this process' device)."""
+    row = (C.c_int * max_devices)()
+    count = int(hip_lib().nb_hip_preflight_peers(row, max_devices))
+    return count, [int(v) for v in row[:min(count, max_devices)]]
+
+
+def preflight_ipc_export(tag):
+    """(hipError_t, 64-byte IPC handle of a device word holding `tag`)."""
+    buf = (C.c_ubyte * 64)()
+    rc = int(hip_lib().nb_hip_preflight_ipc_export(buf, int(tag) & 0xffffffff))
+    return rc, bytes(buf)
+
+
+def preflight_ipc_open(handle, expect_tag):
+    """(0 / hipError_t / -1, host ms) of mapping a peer's exported word, reading it and unmapping."""
+    ms = C.c_double(0.0)
+    buf = (C.c_ubyte * 64).from_buffer_copy(handle)
+    rc = int(hip_lib().nb_hip_preflight_ipc_open(buf, int(expect_tag) & 0xffffffff, C.byref(ms)))
+    return rc, float(ms.value)
+
+
+def hip_error_string(code):
+    return hip_lib().nb_hip_error_string(int(code)).decode(errors="replace")
+
+
 def shard_plan(total_len, mass_len, rank, nranks):
     p = hip_lib().nb_hip_shard_plan(total_len, mass_len, rank, nranks)
     return {n: int(getattr(p, n)) for n, _ in NbShardPlan._fields_}
@@ -312,6 +345,12 @@ class SimPipeline:
         own = hip_lib().nb_hip_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d), C.byref(v), C.byref(ms), path, 256)
         return {"owns_comm": bool(own), "nranks": n.value, "rank": r.value, "device": d.value, "rccl_version": v.value,
                 "first_gather_ms": ms.value, "rccl_lib": path.value.decode()}
+
+    def comm_bringup(self):
+        """nb_hip_comm_bringup: ncclCommInitRank host ms, first all-gather device ms, one warm 8-byte all-gather in device us."""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        own = hip_lib().nb_hip_comm_bringup(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return {"owns_comm": bool(own), "comm_init_ms": a.value, "first_gather_ms": b.value, "small_gather_us": c.value}
 
     def graph_stats(self):
         """cached hipGraph chains and how often a new step size was written to device memory."""

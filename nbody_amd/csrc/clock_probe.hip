@@ -139,7 +139,11 @@ extern "C" int nb_hip_clock_sampler_begin(double period_ms, double max_ms) {
     use_device();
     Sampler &S = g_sampler;
     NB_ASSERT(!S.running, "clock sampler already running");
-    NB_ASSERT(period_ms >= 0.05 && max_ms >= period_ms && max_ms <= 20000.0, "sampler period %g ms, bound %g ms", period_ms, max_ms);
+    // a measurement aid must not take the process down over its own bound: out-of-range requests are clamped (the waves
+    // leave by themselves after max_ms, so a leg longer than the bound is simply sampled over its first 20 s)
+    if (!(period_ms >= 0.05)) period_ms = 0.05;
+    if (!(max_ms <= NB_CLOCK_SAMPLER_MAX_MS)) max_ms = NB_CLOCK_SAMPLER_MAX_MS;
+    if (!(max_ms >= period_ms)) max_ms = period_ms;
     if (hipDeviceGetAttribute(&S.wall_khz, hipDeviceAttributeWallClockRate, g_dev.ordinal) != hipSuccess || S.wall_khz <= 0) {
         (void)hipGetLastError();
         S.wall_khz = 100000;

@@ -4,9 +4,11 @@
 // the reference always takes device 0, vulkan_ctx.c:83-84).  One process drives one GPU; ranks of a sharded run pick
 // theirs with nb_hip_set_device(LOCAL_RANK) before anything touches the device.  Nothing here runs until a pipeline
 // first needs the GPU (SetSimulationData), so CPU-only worlds never initialise HIP.
+#include <chrono>
+
 #include "pipeline_internal.h"
 
-#define NB_HIP_VERSION 300  // 0.3.0: launch-shape / experiment knobs left the ABI (nbody_hip_tuning.h); + nb_hip_probe_clock, nb_hip_clock_sampler_*
+#define NB_HIP_VERSION 301  // 0.3.1: + nb_hip_preflight_* / nb_hip_comm_bringup (multi-GPU bring-up diagnostics that report instead of aborting)
 
 namespace nbi {
 
@@ -87,6 +89,77 @@ void nb_hip_device_info(char *buf, uint32_t len) {
     nbi::ensure_device();
     if (buf && len) snprintf(buf, len, "%s", nbi::g_dev.info);
 }
+
+// ---- preflight: what a harness asks BEFORE the first real contact between ranks; every probe reports, none aborts --------
+
+int nb_hip_preflight_peers(int *row, int len) {
+    nbi::RandGuard keep_callers_rand_stream;  // may be this process' first touch of the GPU
+    nbi::use_device();
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) count = 0;
+    for (int q = 0; row && q < len; q++) {
+        row[q] = -2;  // no such device
+        if (q >= count) continue;
+        int can = 0;
+        if (q == nbi::g_dev.ordinal)
+            row[q] = 1;
+        else if (hipDeviceCanAccessPeer(&can, nbi::g_dev.ordinal, q) == hipSuccess)
+            row[q] = can ? 1 : 0;
+        else {
+            (void)hipGetLastError();
+            row[q] = -1;
+        }
+    }
+    return count;
+}
+
+namespace {
+uint32_t *g_preflight_word = nullptr;  // the 4-byte device word whose IPC handle the probe exports
+}
+
+int nb_hip_preflight_ipc_export(void *handle64, uint32_t tag) {
+    nbi::RandGuard keep_callers_rand_stream;
+    nbi::use_device();
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the preflight ABI carries IPC handles as 64 bytes");
+    hipError_t e = hipSuccess;
+    if (g_preflight_word == nullptr) e = hipMalloc(reinterpret_cast<void **>(&g_preflight_word), 4096);
+    if (e == hipSuccess) e = hipMemcpy(g_preflight_word, &tag, sizeof tag, hipMemcpyHostToDevice);
+    hipIpcMemHandle_t h;
+    memset(&h, 0, sizeof h);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&h, g_preflight_word);
+    if (e != hipSuccess) (void)hipGetLastError();
+    if (handle64) memcpy(handle64, &h, sizeof h);
+    return (int)e;
+}
+
+int nb_hip_preflight_ipc_open(const void *handle64, uint32_t expect_tag, double *ms) {
+    nbi::RandGuard keep_callers_rand_stream;
+    nbi::use_device();
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof h);
+    const auto t0 = std::chrono::steady_clock::now();
+    void *mapped = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&mapped, h, hipIpcMemLazyEnablePeerAccess);
+    uint32_t seen = ~expect_tag;
+    if (e == hipSuccess) e = hipMemcpy(&seen, mapped, sizeof seen, hipMemcpyDeviceToHost);
+    if (mapped) {
+        const hipError_t c = hipIpcCloseMemHandle(mapped);
+        if (e == hipSuccess) e = c;
+    }
+    if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return (int)e;
+    }
+    return seen == expect_tag ? 0 : -1;  // -1: mapped and read, but not the peer's word
+}
+
+void nb_hip_preflight_ipc_release(void) {
+    if (g_preflight_word) (void)hipFree(g_preflight_word);
+    g_preflight_word = nullptr;
+}
+
+const char *nb_hip_error_string(int hip_error) { return hip_error == -1 ? "mapped, but the word read is not the peer's" : hipGetErrorString((hipError_t)hip_error); }
 
 int nb_hip_runtime_version(void) {
     int v = 0;

@@ -73,36 +73,48 @@ void dev_free(void *p);
 // from it (src/bench.c:42,53), between GPU calls.  The HIP runtime's first stream / allocation / code-object set-up
 // draws from (or reseeds) that same process-global state -- measured: tools/rand_probe.py, profiles/r04_rand_probe.txt --
 // so the first device set-up of a pipeline and RCCL's bootstrap run with a private state swapped in.
-// initstate / setstate swap ONE process-global pointer, so two guards alive at once on different threads would hand each
-// other's private state back to the caller (and a rand() on a third thread would draw from whichever is current): the
-// guard therefore holds a process-wide mutex for its lifetime -- device set-up of two pipelines on two threads is
-// serialised, which costs nothing (the HIP runtime serialises it anyway) -- and is recursive on one thread (comm_create
-// runs inside SetSimulationData's guard on some paths).  A caller's own rand() racing a guard on another thread is the
-// caller's race: libc's rand() is not thread-safe to begin with (tests/test_abi.py pins the two-guard case).
+// initstate / setstate swap ONE process-global pointer, so two guards that each saved "the previous state" would hand each
+// other's private state back to the caller.  The guard is therefore reference-counted process-wide: the FIRST guard to
+// come alive saves the caller's state and installs the private one, the LAST to go restores it; the mutex is held only
+// for that bookkeeping, never across the guarded region.  That matters because a guarded region can WAIT ON OTHER RANKS
+// (the direct exchange's IPC-handle hand-over and "ready" barrier run through the caller's all-gather callback inside the
+// first SetSimulationData; ncclCommInitRank blocks until every rank has joined): ranks driven from threads of one process
+// would deadlock on a lock held across such a wait (round 5 held one).  Guards nest freely on one thread.
+// A caller's own rand() racing a live guard on another thread is the caller's race: libc's rand() stream is one
+// process-global object to begin with (tests/test_abi.py pins the two-thread and the wait-inside-a-guard cases).
 class RandGuard {
   public:
     RandGuard() {
-        gate().lock();
-        if (depth()++ == 0) old_ = initstate(1u, buf_, sizeof buf_);
+        std::lock_guard<std::mutex> l(gate());
+        if (alive()++ == 0) saved() = initstate(1u, private_state(), 128);
     }
     ~RandGuard() {
-        if (--depth() == 0 && old_) setstate(old_);
-        gate().unlock();
+        std::lock_guard<std::mutex> l(gate());
+        if (--alive() == 0 && saved()) {
+            setstate(saved());
+            saved() = nullptr;
+        }
     }
     RandGuard(const RandGuard &) = delete;
     RandGuard &operator=(const RandGuard &) = delete;
 
   private:
-    static std::recursive_mutex &gate() {
-        static std::recursive_mutex m;
+    static std::mutex &gate() {
+        static std::mutex m;
         return m;
     }
-    static int &depth() {   // guarded by gate(): nesting depth on the owning thread
-        static int d = 0;
-        return d;
+    static int &alive() {   // guards alive in the process, any thread; guarded by gate()
+        static int n = 0;
+        return n;
     }
-    char buf_[128];
-    char *old_ = nullptr;
+    static char *&saved() {   // the caller's state while alive() > 0
+        static char *p = nullptr;
+        return p;
+    }
+    static char *private_state() {
+        static char buf[128];
+        return buf;
+    }
 };
 
 template <typename T>
@@ -257,6 +269,8 @@ struct SimPipeline {
     std::vector<uint32_t> seen_chains;                  // chain lengths already run once as plain launches
     int want_passes = 0;  // source passes per step (0 = auto: keep each pass's sources within one XCD's L2)
     double first_gather_ms = 0.0;  // sharded: device time of the probe all-gather at creation (includes lazy setup)
+    double comm_init_ms = 0.0;     // sharded over RCCL: host time of ncclCommInitRank
+    double small_gather_us = 0.0;  // sharded over RCCL: device time of one warm 8-byte-per-rank all-gather (mean of 16 in-stream)
     nb::LaunchShape last_shape = {0, 0, 0, 0, 0, 0, 0};
     int want_unit = 0;  // source-slice granule: 0 = auto, else 64 / 32 / 16 / 8
     int want_persist = 0;  // experiment: work items per workgroup of a persistent launch (0 / 1 = classic)

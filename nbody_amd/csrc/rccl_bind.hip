@@ -185,7 +185,9 @@ void comm_create(SimPipeline *s, const void *unique_id128) {
     memcpy(&id, unique_id128, NB_HIP_UNIQUE_ID_BYTES);
     {
         Watchdog dog("ncclCommInitRank", rank, nranks);
+        const auto t0 = std::chrono::steady_clock::now();
         ASSERT_NCCL(rccl().CommInitRank(&s->comm, nranks, id, rank), "ncclCommInitRank(rank %d of %d)", rank, nranks);
+        s->comm_init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     // The communicator's own view must agree with what the caller said: this is what tells N real ranks from N
     // independent replicas.
@@ -219,6 +221,16 @@ void comm_create(SimPipeline *s, const void *unique_id128) {
     float ms = 0.0f;
     ASSERT_HIP(hipEventElapsedTime(&ms, e0, e1), "elapsed");
     s->first_gather_ms = (double)ms;
+    // ... and what a WARM small all-gather costs in-stream: 16 back-to-back 8-byte-per-rank gathers between one event pair.
+    // This is the fixed cost of the per-step gather -- the one term of the scaling curve a single-GPU box cannot measure.
+    const int reps = 16;
+    ASSERT_HIP(hipEventRecord(e0, st), "record");
+    for (int i = 0; i < reps; i++)
+        ASSERT_NCCL(rccl().AllGather(probe + (size_t)rank * 2, probe, 2, NCCL_FLOAT32, s->comm, st), "8-byte ncclAllGather");
+    ASSERT_HIP(hipEventRecord(e1, st), "record");
+    ASSERT_HIP(hipStreamSynchronize(st), "8-byte gathers");
+    ASSERT_HIP(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+    s->small_gather_us = (double)ms * 1e3 / reps;
     ASSERT_HIP(hipEventDestroy(e0), "event");
     ASSERT_HIP(hipEventDestroy(e1), "event");
     ASSERT_HIP(hipStreamDestroy(st), "probe stream");
@@ -246,6 +258,14 @@ void nb_hip_comm_unique_id(void *out128) {
     ncclUniqueId id;
     ASSERT_NCCL(rccl().GetUniqueId(&id), "ncclGetUniqueId");
     memcpy(out128, &id, NB_HIP_UNIQUE_ID_BYTES);
+}
+
+int nb_hip_comm_bringup(const SimPipeline *s, double *init_ms, double *first_gather_ms, double *small_gather_us) {
+    NB_ASSERT(s != nullptr, "NULL pipeline");
+    if (init_ms) *init_ms = s->comm_init_ms;
+    if (first_gather_ms) *first_gather_ms = s->first_gather_ms;
+    if (small_gather_us) *small_gather_us = s->small_gather_us;
+    return s->comm != nullptr;
 }
 
 int nb_hip_comm_info(const SimPipeline *s, int *nranks, int *rank, int *device, int *rccl_version, double *first_gather_ms,

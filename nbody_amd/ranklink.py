@@ -13,7 +13,8 @@ Who may connect, and what may be sent:
     cannot reach it, and two runs with the same name collide loudly at bind() instead of cross-connecting;
   * both ends check SO_PEERCRED: the peer's uid must be ours;
   * every peer answers the hub's hello with sha256(name | hub pid | nonce | rank) before it is admitted -- a stray
-    process of the same user that connects by accident is refused;
+    process of the same user that connects by accident is refused: it gets HELLO_TIMEOUT_S to answer, and silence, garbage
+    or a wrong token closes THAT connection only (the hub keeps accepting until its own deadline);
   * the wire format is fixed (a one-byte tag + lengths; None, bytes, int64, a list of float64, one level of list): nothing
     received is ever executed or unpickled.
 """
@@ -27,6 +28,7 @@ import time
 
 _MAX_MESSAGE = 1 << 32      # bytes; the largest real message is a few MiB of particle slices
 _MAX_ITEMS = 1 << 16
+HELLO_TIMEOUT_S = 5.0       # what one connecting peer gets to answer the hub's hello
 
 
 def encode(obj, _depth=0):
@@ -41,12 +43,12 @@ def encode(obj, _depth=0):
     if isinstance(obj, int):
         return b"I" + struct.pack("<q", obj)
     if isinstance(obj, (list, tuple)):
+        if len(obj) > _MAX_ITEMS:
+            raise ValueError("ranklink list too long")       # the receiver would refuse it: fail at the sender
         if all(isinstance(v, float) for v in obj) and len(obj) > 0:
             return b"F" + struct.pack("<I", len(obj)) + struct.pack("<%dd" % len(obj), *obj)
         if _depth >= 1:
             raise TypeError("ranklink lists nest one level only")
-        if len(obj) > _MAX_ITEMS:
-            raise ValueError("ranklink list too long")
         return b"L" + struct.pack("<I", len(obj)) + b"".join(encode(v, _depth + 1) for v in obj)
     raise TypeError("ranklink carries None, bytes, int, float lists and lists of those, not %s" % type(obj).__name__)
 
@@ -138,22 +140,34 @@ class RankLink:
                     srv.bind(path)
             self.path = path
             srv.listen(world)
-            srv.settimeout(timeout_s)
             nonce = os.urandom(16)
             try:
                 while len(self.peers) < world - 1:
-                    conn, _ = srv.accept()
+                    left = deadline - time.monotonic()
+                    if left <= 0:
+                        raise TimeoutError(f"rank 0: {world - 1 - len(self.peers)} of {world - 1} peers never reached the hub "
+                                           f"at {path!r} within {timeout_s} s")
+                    srv.settimeout(left)
+                    try:
+                        conn, _ = srv.accept()
+                    except socket.timeout:
+                        continue          # the loop's own deadline check words the error
+                    # one connection's hello must not hold the hub: a short per-connection bound, and anything that is not
+                    # a well-formed answer from a peer of this run closes that connection only
+                    try:
+                        conn.settimeout(min(HELLO_TIMEOUT_S, max(left, 0.1)))
+                        if _peer_uid(conn)[0] != os.getuid():
+                            raise ConnectionError("peer of another uid")
+                        self._send(conn, nonce)
+                        hello = self._recv(conn)
+                        ok = (isinstance(hello, list) and len(hello) == 2 and isinstance(hello[0], int) and 0 < hello[0] < world
+                              and hello[0] not in self.peers and hello[1] == _token(name, os.getpid(), nonce, hello[0]))
+                        if not ok:
+                            raise ConnectionError("not a peer of this run")
+                    except (ValueError, OSError):   # ConnectionError and socket.timeout are OSErrors; decode() raises ValueError
+                        conn.close()
+                        continue
                     conn.settimeout(timeout_s)
-                    if _peer_uid(conn)[0] != os.getuid():
-                        conn.close()
-                        continue
-                    self._send(conn, nonce)
-                    hello = self._recv(conn)
-                    ok = (isinstance(hello, list) and len(hello) == 2 and isinstance(hello[0], int) and 0 < hello[0] < world
-                          and hello[0] not in self.peers and hello[1] == _token(name, os.getpid(), nonce, hello[0]))
-                    if not ok:
-                        conn.close()
-                        continue
                     self.peers[hello[0]] = conn
             finally:
                 srv.close()

@@ -329,7 +329,7 @@ int main(int argc, char **argv) {
         });
         while (stage.load() == 0) nap(1);
         {
-            RandGuard mine;              // second guard on another thread: must wait for the first, not capture its private state
+            RandGuard mine;              // second guard on another thread: must not capture the first one's private state
             RandGuard nested;            // and the same thread may nest (comm_create inside SetSimulationData)
             (void)rand();
         }
@@ -338,6 +338,30 @@ int main(int argc, char **argv) {
         for (int i = 0; i < 3; i++)
             if (got[i] != want[i]) { printf("rand stream disturbed: draw %d is %d, expected %d\n", i, got[i], want[i]); return 1; }
         printf("rand stream intact\n");
+        return 0;
+    }
+    if (mode == "rand_wait") {
+        // two "ranks" on two threads, each inside its first-touch guard, meet at a barrier INSIDE the guarded region (the
+        // direct exchange's IPC hand-over runs through the caller's all-gather callback there): must not deadlock
+        srand(321);
+        const int want[2] = {rand(), rand()};
+        srand(321);
+        std::atomic<int> arrived{0};
+        auto rank = [&] {
+            RandGuard first_touch;
+            (void)rand();
+            arrived++;
+            for (int i = 0; i < 3000 && arrived.load() < 2; i++) nap(1);   // the "callback": waits for the peer, 3 s at most
+            RandGuard nested;
+            (void)rand();
+        };
+        std::thread a(rank), b(rank);
+        a.join();
+        b.join();
+        if (arrived.load() != 2) { printf("a rank never reached the barrier\n"); return 1; }
+        const int got[2] = {rand(), rand()};
+        if (got[0] != want[0] || got[1] != want[1]) { printf("rand stream disturbed\n"); return 1; }
+        printf("ranks met inside their guards; rand stream intact\n");
         return 0;
     }
     if (mode == "watch") {
@@ -382,11 +406,21 @@ def helpers_exe(tmp_path_factory):
 
 def test_rand_guards_on_two_threads_leave_the_callers_stream_alone(helpers_exe):
     """RandGuard (pipeline_internal.h) swaps libc's process-global random state around the first device set-up; two guards
-    alive at once on two threads must not hand each other's private state back to the caller: the guard is serialised by a
-    process-wide (recursive) mutex.  The reference harness draws its universes from rand() between GPU calls
-    (src/bench.c:42,53)."""
+    alive at once on two threads must not hand each other's private state back to the caller: the guard is counted
+    process-wide (first in saves the caller's state, last out restores it).  The reference harness draws its universes from
+    rand() between GPU calls (src/bench.c:42,53)."""
     r = subprocess.run([helpers_exe, "rand"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "rand stream intact" in r.stdout, (r.stdout, r.stderr)
+
+
+def test_ranks_on_threads_can_wait_for_each_other_inside_their_rand_guards(helpers_exe):
+    """SetSimulationData's first-touch guard spans the caller's all-gather callback (IPC-handle exchange, "ready"
+    barrier).  Two ranks driven from two threads of one process must be able to meet there: no lock is held across the
+    guarded region, and the caller's rand() stream is still intact afterwards."""
+    import time
+    t0 = time.time()
+    r = subprocess.run([helpers_exe, "rand_wait"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "ranks met inside their guards" in r.stdout and time.time() - t0 < 2.5, (r.stdout, r.stderr)
 
 
 def test_watchdog_watches_waits_on_every_thread(helpers_exe):

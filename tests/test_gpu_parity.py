@@ -1750,6 +1750,19 @@ def test_bench_with_two_real_ranks_on_one_gpu(transport):
     timed = [e for e in extra if "skipped" not in e]
     assert all(e["value"] > 1e10 and e["kernel_ms_per_step"]["max"] > 0 for e in timed)
     assert "extras_aborted" not in out
+    # preflight: every rank's bring-up record, written before the headline -- PCI address, the
+    # hipDeviceCanAccessPeer row, and (direct only: the host transport must not depend on IPC) one IPC open / close of the
+    # next rank's exported word
+    flights = out["preflight"]
+    assert [f["rank"] for f in flights] == [0, 1] and all(f["transport"] == transport for f in flights)
+    assert len({f["pci"] for f in flights}) == 1 and all(f["visible_devices"] >= 1 and f["can_access_peer"][0] == 1 for f in flights)
+    if transport == "direct":
+        assert all(f["ipc_export_rc"] == 0 and f["ipc_open_rc"] == 0 and f["ipc_open_peer"] == 1 - f["rank"] and f["ipc_open_ms"] > 0 for f in flights)
+    else:
+        assert all("ipc_open_rc" not in f for f in flights)
+    trail = out["launch"]["attempts"][0]["preflight"]            # what the supervisors read off the workers' stderr, stage by stage
+    assert {e["stage"] for e in trail} == ({"device", "ipc"} if transport == "direct" else {"device"})
+    assert 0 < out["roofline"]["roofline_frac_from_wall"] < 1 and out["roofline"]["traffic_measured_in_this_run"] is False
 
 
 def test_bench_line_survives_a_stuck_leg():
@@ -1758,15 +1771,14 @@ def test_bench_line_survives_a_stuck_leg():
     the line with what is in hand plus "extras_aborted" and every rank leaves with a fresh non-zero exit.  Rehearsed
     with two real ranks on this one GPU: during the 'overlap' leg the host transport's all-gather never returns."""
     import json
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", NB_BENCH_REHEARSE='{"stall_leg": "overlap"}')
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29743", os.path.join(nb.ROOT, "bench.py"), "--gpus", "2", "--transport", "host",
-           "--steps", "4", "--warmup", "1", "--particles", "65536", "--extra-particles", "131072",
-           "--stall-leg", "overlap", "--leg-deadline-s", "10"]
+           "--steps", "4", "--warmup", "1", "--particles", "65536", "--extra-particles", "131072", "--leg-deadline-s", "10"]
     t0 = time.time()
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=nb.ROOT)
     assert r.returncode != 0, "a run whose leg stalled must not report success"
-    assert time.time() - t0 < 300, "the deadline, not the 900 s gloo timeout, must end the run"
+    assert time.time() - t0 < 300, "the leg's deadline, not the run's budget, must end the run"
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
     out = json.loads(lines[0])
@@ -1781,10 +1793,10 @@ def test_bench_line_survives_a_leg_that_aborts():
     """... and not to an optional leg that dies by the library's own error convention (print + abort(), reference
     src/lib/util.h:17-29) either: rank 0's C-level handler writes the line prepared when the leg was armed."""
     import json
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", NB_BENCH_REHEARSE='{"crash_leg": "config5"}')
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29745", os.path.join(nb.ROOT, "bench.py"), "--gpus", "2", "--transport", "host",
-           "--steps", "4", "--warmup", "1", "--particles", "65536", "--extra-particles", "131072", "--crash-leg", "config5"]
+           "--steps", "4", "--warmup", "1", "--particles", "65536", "--extra-particles", "131072"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=nb.ROOT)
     assert r.returncode != 0
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -1795,6 +1807,33 @@ def test_bench_line_survives_a_leg_that_aborts():
     # the leg that had finished before the crash is on the line: the overlapped step
     assert [(e["overlap"], e["sharded_graph"]) for e in out["extra_configs"]] == [(1, 0)]
     assert "fatal signal 6" in r.stderr
+
+
+def test_bench_auto_lands_on_the_host_transport_when_rccl_and_direct_are_refused():
+    """--transport auto with two real ranks on this ONE GPU: RCCL refuses the duplicate device for real (both ranks abort in
+    ncclCommInitRank), the direct attempt is made to fail right after its rendezvous (tests/bench_rehearsal.py), and the run
+    lands on the transport nothing can refuse -- host-staged slices over the rank link -- with two transport_fallback
+    entries, a verified headline and exit code 0.  Each failed attempt leaves its preflight trail."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(OMP_NUM_THREADS="4", NB_BENCH_REHEARSE='{"fail_transports": ["direct"]}')
+    r = subprocess.run([sys.executable, os.path.join(nb.ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--particles", "65536", "--extra-particles", "131072", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=nb.ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert [a["transport"] for a in out["launch"]["attempts"]] == ["rccl", "direct", "host"]
+    fb = out["transport_fallback"]
+    assert [(f["from"], f["to"], f["kind"]) for f in fb] == [("rccl", "direct", "bring_up_failed"), ("direct", "host", "bring_up_failed")]
+    assert out["transport"].startswith("host") and out["n_gpus"] == 2 and out["value"] > 1e10
+    check = out["self_check"]
+    assert check["ranks_agree"] is True and check["ok"] is True and check["vs_single_gpu_rel_l2_pos"] <= 1e-6
+    # the RCCL attempt got as far as its IPC probe and announced ncclCommInitRank before it died there
+    trail = out["launch"]["attempts"][0]["preflight"]
+    assert any(e.get("stage") == "rccl" and "entering" in e for e in trail) and any(e.get("stage") == "ipc" and e.get("ipc_open_rc") == 0 for e in trail)
+    assert out["launch"]["seconds"] < out["launch"]["budget_s"]
 
 
 def test_host_transport_callback_that_raises_ends_the_process(golden, tmp_path):
@@ -1887,8 +1926,9 @@ def test_single_gpu_bench_line_survives_a_leg_that_aborts(leg):
     library's error convention (print + abort(), reference src/lib/util.h:17-29) still leaves the headline on stdout, once,
     with "extras_aborted" naming the leg, and the run does not report success."""
     import json
-    r = subprocess.run([sys.executable, os.path.join(nb.ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                        "--crash-leg", leg], capture_output=True, text=True, timeout=600, cwd=nb.ROOT)
+    env = dict(os.environ, NB_BENCH_REHEARSE=json.dumps({"crash_leg": leg}))
+    r = subprocess.run([sys.executable, os.path.join(nb.ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=nb.ROOT)
     assert r.returncode == 6, (r.returncode, r.stderr[-1500:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-1000:]

@@ -91,54 +91,132 @@ def test_bench_started_bare_spawns_its_own_ranks(world):
     out = _one_json_line(r.stdout)
     assert out["n_gpus"] == world and out["self_check"]["ranks_agree"] is True
     assert out["launch"]["mode"].startswith("bare") and len(out["launch"]["attempts"]) == 1
-    assert out["launch"]["attempts"][0] == {"transport": "rccl", "child_rcs": [0] * world,
-                                            "seconds": out["launch"]["attempts"][0]["seconds"]}
-    assert "transport_fallback" not in out and out["transport"].startswith("rccl")
+    first = out["launch"]["attempts"][0]
+    assert first["transport"] == "rccl" and first["child_rcs"] == [0] * world and "kind" not in first
+    assert 0 < first["seconds"] < first["limit_s"] < out["launch"]["budget_s"] == 480.0       # the attempt's share of ONE budget
+    # every rank's bring-up record: on the attempt (what the supervisor read off the workers' stderr) and on the line
+    assert sorted(e["rank"] for e in first["preflight"]) == list(range(world))
+    assert [e["rank"] for e in out["preflight"]] == list(range(world)) and all(e["transport"] == "rccl" for e in out["preflight"])
+    assert "transport_fallback" not in out and "verification_failed" not in out and out["transport"].startswith("rccl")
 
 
-@pytest.mark.parametrize("launcher", ["bare", "torchrun"])
-def test_bench_falls_back_to_the_direct_exchange_in_fresh_processes(launcher):
-    """--transport auto (the default): when a rank of the RCCL attempt leaves before the headline is in hand -- rehearsed: the
-    last rank exits with 3 right after the rendezvous, what the library's watchdog does when ncclCommInitRank never
-    completes -- the supervisor ends the attempt's other ranks by exact pid, starts a FRESH set of rank processes over the
-    direct exchange and stamps the line.  Same behaviour whether bench.py spawned the ranks itself or
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "NB_BENCH_REHEARSE")}
+    env["OMP_NUM_THREADS"] = "2"
+    env.update(extra)
+    return env
+
+
+def _bench_cmd(launcher, world, port, *flags):
+    root = os.path.dirname(HERE)
+    tail = [os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--particles", "65536",
+            "--extra-particles", "131072", "--dry-run", "--no-extras"] + list(flags)
+    if launcher == "bare":
+        return [sys.executable] + tail
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port)] + tail
+
+
+@pytest.mark.parametrize("launcher,world", [("bare", 2), ("bare", 8), ("torchrun", 3)])
+def test_bench_walks_the_transport_chain_in_fresh_processes(launcher, world):
+    """--transport auto (the default) = rccl -> direct -> host: when a rank of an attempt leaves before the headline is in
+    hand -- rehearsed through tests/bench_rehearsal.py: the last rank of the rccl AND of the direct attempt exits with 3 right
+    after the rendezvous, what the library's watchdog does when a bring-up never completes -- the supervisor ends the
+    attempt's other ranks by exact pid, starts a FRESH set of rank processes over the next transport and stamps the line with
+    one transport_fallback entry per step.  Same behaviour whether bench.py spawned the ranks itself or
     torch.distributed.run did (then every rank process is a GPU-free supervisor of one worker)."""
     root = os.path.dirname(HERE)
-    world = 3
-    tail = [os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--particles", "65536",
-            "--extra-particles", "131072", "--dry-run", "--no-extras", "--rehearse-rccl-failure"]
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
-    env["OMP_NUM_THREADS"] = "2"
-    if launcher == "bare":
-        cmd = [sys.executable] + tail
-    else:
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-               "--master-port", "29677"] + tail
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    env = _clean_env(NB_BENCH_REHEARSE='{"fail_transports": ["rccl", "direct"]}')
+    r = subprocess.run(_bench_cmd(launcher, world, 29677), env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     out = _one_json_line(r.stdout)
-    first, second = out["launch"]["attempts"]
-    assert first["transport"] == "rccl" and first["child_rcs"][world - 1] == 3 and any(rc != 0 for rc in first["child_rcs"])
-    assert second["transport"] == "direct" and second["child_rcs"] == [0] * world
+    a1, a2, a3 = out["launch"]["attempts"]
+    assert [a["transport"] for a in (a1, a2, a3)] == ["rccl", "direct", "host"]
+    for a in (a1, a2):
+        assert a["kind"] == "bring_up_failed" and a["child_rcs"][world - 1] == 3 and a["why_not"]
+    assert a3["child_rcs"] == [0] * world and "kind" not in a3
+    assert a1["limit_s"] > a2["limit_s"] * 0.9 and a3["limit_s"] > a2["limit_s"]       # 1/2, 1/2 of the rest, then all of the rest
     fb = out["transport_fallback"]
-    assert fb["from"] == "rccl" and fb["to"] == "direct" and fb["rc"] == first["child_rcs"] and fb["why"]
-    assert "rc 3" in fb["stderr_tail"] or "exit 3" in fb["stderr_tail"]
-    assert out["transport"].startswith("direct") and out["n_gpus"] == world and out["self_check"]["ranks_agree"] is True
-    assert out["extra_configs"] == []       # --no-extras keeps the self-check and drops the optional legs
+    assert [(f["from"], f["to"], f["kind"]) for f in fb] == [("rccl", "direct", "bring_up_failed"), ("direct", "host", "bring_up_failed")]
+    assert all(f["rc"][world - 1] == 3 and ("rc 3" in f["stderr_tail"] or "exit 3" in f["stderr_tail"]) for f in fb)
+    assert out["transport"].startswith("host") and out["n_gpus"] == world and out["self_check"]["ranks_agree"] is True
+    assert out["extra_configs"] == [] and "verification_failed" not in out      # --no-extras keeps the self-check, drops the legs
 
 
 def test_bench_supervisor_reports_when_no_attempt_delivers():
     """An explicit --transport rccl has no fallback: the rehearsed failure ends the run with ONE line that says so (value
     null, the attempt's exit codes) and a non-zero exit code."""
     root = os.path.dirname(HERE)
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--particles", "65536",
-                        "--dry-run", "--no-extras", "--rehearse-rccl-failure", "--transport", "rccl"],
-                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    env = _clean_env(NB_BENCH_REHEARSE='{"fail_transports": ["rccl"]}')
+    r = subprocess.run(_bench_cmd("bare", 2, 0, "--transport", "rccl"), env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode != 0
     out = _one_json_line(r.stdout)
     assert out["value"] is None and out["error"] and out["launch"]["attempts"][0]["child_rcs"][1] == 3
     assert len(out["launch"]["attempts"]) == 1 and "transport_fallback" not in out
+
+
+@pytest.mark.parametrize("launcher,world", [("bare", 2), ("bare", 8), ("torchrun", 2)])
+def test_bench_budget_ends_a_hung_run_with_a_line(launcher, world):
+    """ONE total budget (--budget-s, default 480 s: under the 600 s a driver allows the command): every attempt's limit is
+    carved from what is left.  Rehearsed: every rank of every attempt hangs right after the rendezvous (a first barrier that
+    never completes).  The supervisor ends each attempt's ranks by exact pid when its share is used up, walks the whole chain,
+    and the run still prints ONE line -- value null, the three attempts, why -- inside the budget, with a non-zero exit code
+    (round 5 waited 900 s per attempt)."""
+    import time
+    root = os.path.dirname(HERE)
+    env = _clean_env(NB_BENCH_REHEARSE='{"hang": true}')
+    t0 = time.time()
+    r = subprocess.run(_bench_cmd(launcher, world, 29679, "--budget-s", "30"), env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    took = time.time() - t0
+    assert r.returncode != 0
+    out = _one_json_line(r.stdout)
+    assert out["value"] is None and "share of the budget" in out["error"]
+    attempts = out["launch"]["attempts"]
+    assert [a["transport"] for a in attempts] == ["rccl", "direct", "host"] and all(a["kind"] == "timed_out" for a in attempts)
+    assert all(rc == -9 for a in attempts for rc in a["child_rcs"])                  # ended by the supervisor, by pid
+    assert sum(a["seconds"] for a in attempts) <= 30.0 and out["launch"]["seconds"] <= 30.0
+    assert took < (32.0 if launcher == "bare" else 45.0)                              # torchrun's own start-up is not ours to budget
+    assert [(f["from"], f["to"], f["kind"]) for f in out["transport_fallback"]] == [("rccl", "direct", "timed_out"), ("direct", "host", "timed_out")]
+
+
+def test_bench_a_failed_self_check_is_not_a_bring_up_failure():
+    """a wrong answer on the product transport must not end as exit 0 with a fallback comment.  Rehearsed: the rccl
+    attempt delivers a complete line whose self-check says the ranks DISAGREE.  The supervisor still tries the next transport
+    (the run yields a verified number), but the line carries "verification_failed" with the failed check, the fallback entry
+    says kind = verification_failed -- not bring_up_failed -- and the exit code is non-zero."""
+    root = os.path.dirname(HERE)
+    env = _clean_env(NB_BENCH_REHEARSE='{"bad_self_check": ["rccl"]}')
+    r = subprocess.run(_bench_cmd("bare", 2, 0), env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 5, (r.returncode, r.stderr[-2000:])
+    out = _one_json_line(r.stdout)
+    assert out["transport"].startswith("direct") and out["self_check"]["ranks_agree"] is True
+    assert [v["transport"] for v in out["verification_failed"]] == ["rccl"] and out["verification_failed"][0]["self_check"]["ranks_agree"] is False
+    assert [(f["from"], f["to"], f["kind"]) for f in out["transport_fallback"]] == [("rccl", "direct", "verification_failed")]
+    assert out["launch"]["attempts"][0]["child_rcs"] == [0, 0]                       # nothing crashed: it was the CHECK that failed
+    # ... and with no fallback to make, the unverified number is not printed as the result at all
+    r = subprocess.run(_bench_cmd("bare", 2, 0, "--transport", "rccl"), env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 5
+    out = _one_json_line(r.stdout)
+    assert out["value"] is None and out["error"].startswith("self_check failed") and out["verification_failed"][0]["transport"] == "rccl"
+
+
+def test_bench_help_lists_no_rehearsal_flag_and_the_rehearsals_live_with_the_tests():
+    """the timed tool carries no test-only flag or branch; the hooks are observers registered by
+    tests/bench_rehearsal.py when NB_BENCH_REHEARSE is set, and an unknown rehearsal is refused loudly."""
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "--budget-s" in r.stdout
+    for word in ("--rehearse", "--stall", "--crash", "attempt-timeout"):
+        assert word not in r.stdout
+    src = open(os.path.join(root, "bench.py")).read()
+    assert len(src.splitlines()) < 1200
+    assert "os.abort" not in src and "rehearse_" not in src and "time.sleep(60" not in src and "time.sleep(3600" not in src
+    sys.path.insert(0, root)
+    import bench
+    assert bench.OBSERVERS == []
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dry-run"], env=_clean_env(NB_BENCH_REHEARSE='{"typo": 1}'),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "unknown keys" in r.stderr
 
 
 def test_bench_traffic_figure_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
@@ -162,7 +240,8 @@ def test_bench_traffic_figure_is_tied_to_the_kernel_sources(tmp_path, monkeypatc
         assert bench.pmc_traffic(1 << 20, launch, passes)[0] == rec["hbm_bytes_per_launch"]
     assert bench.pmc_traffic(1 << 20, dict(launch, split=launch["split"] + 1), passes)[1].startswith("stale: this run launched")
     assert bench.pmc_traffic(1 << 20, launch, passes + 1)[0] is None
-    monkeypatch.setattr(bench, "kernel_sources_sha", lambda: "0" * 64)
+    import nbody_amd.benchlib as benchlib
+    monkeypatch.setattr(benchlib, "kernel_sources_sha", lambda: "0" * 64)
     value, note = bench.pmc_traffic(1 << 20)
     assert value is None and note.startswith("stale")
     assert bench.pmc_traffic(12345)[0] is None
@@ -353,6 +432,79 @@ def test_rank_link_socket_lives_in_a_private_directory_and_refuses_strangers(tmp
     assert not os.path.exists(path)             # the name is free again once everybody is connected
 
 
+def test_rank_link_hub_survives_silent_and_garbage_peers():
+    """a same-uid stray that connects and stays silent gets HELLO_TIMEOUT_S, not the hub's whole timeout; one that
+    sends bytes that are not a message (decode raises ValueError) or a frame that is too long is closed -- and in every case
+    the hub keeps accepting, so the real rank still gets in."""
+    import socket
+    import struct
+    import threading
+    import time
+    from nbody_amd import ranklink as rl
+    name = f"nbody_test_strays_{os.getpid()}"
+    result = {}
+
+    def hub():
+        t0 = time.time()
+        link = rl.RankLink(0, 2, name=name, timeout_s=60)
+        result["admitted_after"] = time.time() - t0
+        result["gathered"] = link.allgather(b"hub")
+        link.close()
+
+    old = rl.HELLO_TIMEOUT_S
+    rl.HELLO_TIMEOUT_S = 1.0
+    try:
+        t = threading.Thread(target=hub)
+        t.start()
+        path = os.path.join(rl.socket_dir(), name + ".sock")
+        for _ in range(500):
+            if os.path.exists(path):
+                break
+            time.sleep(0.01)
+        silent = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        silent.connect(path)                       # says nothing: the hub must move on after HELLO_TIMEOUT_S
+        garbage = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        garbage.connect(path)
+        garbage.sendall(struct.pack("<Q", 3) + b"XYZ")                  # a frame that is not a message
+        huge = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        huge.connect(path)
+        huge.sendall(struct.pack("<Q", 1 << 40))                        # a frame longer than any message
+        peer = rl.RankLink(1, 2, name=name, timeout_s=60)
+        assert peer.allgather(b"peer") == [b"hub", b"peer"]
+        peer.close()
+        t.join(30)
+    finally:
+        rl.HELLO_TIMEOUT_S = old
+    assert result["gathered"] == [b"hub", b"peer"] and result["admitted_after"] < 10.0
+    for s_ in (silent, garbage, huge):
+        s_.close()
+    # a float list the receiver would refuse fails at the SENDER
+    with pytest.raises(ValueError):
+        rl.encode([0.0] * (rl._MAX_ITEMS + 1))
+    # a hub nobody joins gives up at its own deadline with a message that says how many peers are missing
+    with pytest.raises(TimeoutError, match="1 of 1 peers never reached the hub"):
+        rl.RankLink(0, 2, name=name + "_alone", timeout_s=0.5)
+
+
+def test_clock_sampler_bound_is_clamped_not_asserted():
+    """bench.py asked the sampler for 3 x the headline leg + 0.5 s without a bound while the library asserted
+    max_ms <= 20 000: a leg of ~6.5 s aborted the run.  Now the library clamps (a measurement aid never takes the process
+    down over its own bound), the bound is one named constant in the header, and bench.py stays below it by itself."""
+    import re
+    root = os.path.dirname(HERE)
+    import nbody_amd as nb
+    header = open(os.path.join(root, "include", "nbody_hip.h")).read()
+    assert float(re.search(r"#define NB_CLOCK_SAMPLER_MAX_MS ([0-9.]+)", header).group(1)) == nb.CLOCK_SAMPLER_MAX_MS == 20000.0
+    src = open(os.path.join(root, "nbody_amd", "csrc", "clock_probe.hip")).read()
+    begin = src[src.index('extern "C" int nb_hip_clock_sampler_begin'):]
+    begin = begin[:begin.index("hipLaunchKernelGGL")]
+    assert "NB_ASSERT(period_ms" not in begin and "max_ms = NB_CLOCK_SAMPLER_MAX_MS" in begin
+    bench_src = open(os.path.join(root, "bench.py")).read()
+    assert "min(nb.CLOCK_SAMPLER_MAX_MS, 3.0 * elapsed * 1e3 + 500.0)" in bench_src
+    for elapsed_s in (0.1, 1.95, 6.5, 7.0, 400.0):       # 20 steps at 97 ms, ~70 steps, --particles 4194304 ...
+        assert min(nb.CLOCK_SAMPLER_MAX_MS, 3.0 * elapsed_s * 1e3 + 500.0) <= 20000.0
+
+
 def test_bench_pure_helpers_for_the_round5_line():
     """The arithmetic bench.py puts on the line, checked without a GPU: cycles per wave-interaction from kernel seconds and
     the held clock, the fraction of the instruction mix's 26-cycle floor, the gather estimate with its stated parts, the
@@ -398,9 +550,9 @@ def test_bench_supervisor_takes_its_ranks_with_it_when_told_to_stop():
     import time
     import psutil
     root = os.path.dirname(HERE)
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
-    sup = subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--particles", "65536", "--dry-run",
-                            "--rehearse-hang"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root)
+    env = _clean_env(NB_BENCH_REHEARSE='{"hang": true}')
+    sup = subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--particles", "65536", "--dry-run"],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root)
     kids = []
     for _ in range(200):
         kids = psutil.Process(sup.pid).children(recursive=True)
@@ -414,8 +566,8 @@ def test_bench_supervisor_takes_its_ranks_with_it_when_told_to_stop():
     gone, alive = psutil.wait_procs(kids, timeout=10)
     assert not alive, alive
     # ... and not even a SIGKILL of the supervisor leaves them behind (PR_SET_PDEATHSIG in every rank process)
-    sup = subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--particles", "65536", "--dry-run",
-                            "--rehearse-hang"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root)
+    sup = subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--particles", "65536", "--dry-run"],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root)
     for _ in range(200):
         kids = psutil.Process(sup.pid).children(recursive=True)
         if len(kids) == 2:
