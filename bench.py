@@ -1072,6 +1072,23 @@ def shard_leg(nb, name, part, m, ranks, steps, t1_ms=None, stamp=True):
         entry["predicted_scaling_efficiency"] = t1_ms / (ranks * (shard_ms + gather_ms))
     if stamp:
         entry["parity"] = parity_stamp(grp, m)
+    if ranks > 1:
+        # What would the OVERLAPPED step cost this rank?  Own-shard kernel + remote-shards kernel instead of one: the sum of the
+        # two against the one above is what overlap must win back by hiding the gather.  So the first measured plain
+        # comm_ms_per_step of a real multi-GPU run decides the sharded default by comparison with ONE number (DESIGN.md
+        # section 4): overlap pays when the gather it hides is longer than overlap_break_even_gather_ms.
+        for mem in grp.members:
+            mem.configure(overlap=1)
+        grp.step(1, DT)
+        grp.step(steps, DT)
+        both = []
+        for mem in grp.members:
+            covered, k_ms, _ = mem.step_breakdown()
+            both.append(k_ms / max(covered, 1))
+        entry["overlap_kernels_ms_per_step"] = {"min": min(both), "max": max(both), "mean": sum(both) / len(both)}
+        entry["overlap_break_even_gather_ms"] = max(both) - shard_ms
+        entry["overlap_note"] = ("own-shard + remote-shards kernels of the overlapped step, summed, minus the one kernel of the plain step: "
+                                 "what hiding the gather must win back; compare with a real run's plain comm_ms_per_step")
     grp.close()
     return entry
 

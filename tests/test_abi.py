@@ -304,6 +304,30 @@ def test_nbody_bench_rejects_a_captured_graph_over_the_host_transport():
     assert r.returncode == 2 and "graph needs --transport rccl" in r.stderr
 
 
+def test_nbody_bench_walks_rccl_ipc_shm_in_fresh_ranks_and_keeps_the_users_timeout():
+    """nbody-bench --gpus P --transport auto = rccl -> ipc -> shm, every attempt in freshly forked ranks.
+    Without a GPU every attempt's ranks leave with status 2 (no device), which is enough to see the chain: three attempts, two
+    transport_fallback lines naming bring_up_failed, the last attempt's status as the exit code -- and an explicit transport
+    makes one attempt only.  A NB_HIP_COMM_TIMEOUT_S the user exported is neither overwritten nor unset."""
+    nb.nbody_lib()
+    env = dict(os.environ, NB_HIP_COMM_TIMEOUT_S="33")
+    r = subprocess.run([BENCH_EXE, "--gpus", "2", "--n", "4096", "--steps", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2, (r.stdout, r.stderr)
+    marks = [l for l in r.stdout.splitlines() if l.startswith("# transport_fallback")]
+    assert [m.split("(")[0].strip() for m in marks] == ["# transport_fallback rccl -> ipc", "# transport_fallback ipc -> shm"]
+    assert all("bring_up_failed, status 2" in m for m in marks)
+    for name, need in (("rccl", "needs 2 (one per rank)"), ("ipc", "needs 1"), ("shm", "needs 1")):
+        assert f"--transport {name} {need}" in r.stderr
+    assert "verification_failed" not in r.stdout + r.stderr
+    r = subprocess.run([BENCH_EXE, "--gpus", "2", "--n", "4096", "--transport", "shm"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "transport_fallback" not in r.stdout + r.stderr and r.stderr.count("--transport shm needs 1") == 2
+    src = open(os.path.join(ROOT, "nbody_amd", "csrc", "bench_main.c")).read()
+    assert 'if (!timeout_is_the_users) unsetenv("NB_HIP_COMM_TIMEOUT_S")' in src and src.count('unsetenv("NB_HIP_COMM_TIMEOUT_S")') == 1
+    # a budget too small for any attempt still ends with a line that says so, and a non-zero status
+    r = subprocess.run([BENCH_EXE, "--gpus", "2", "--n", "4096", "--budget-s", "8"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 4 and "# budget of 8 s used up before the rccl attempt" in r.stdout
+
+
 # ---- internal C++ helpers with process-global state, pinned without a GPU (ADVICE r4) -----------------------------------
 
 HELPERS_SRC = r'''

@@ -1635,6 +1635,9 @@ def test_nbody_bench_c_falls_back_to_the_direct_exchange_in_fresh_ranks():
     assert [(x[0], x[2]) for x in rows] == [("20000", "plain"), ("20000", "overlap")] and all(float(x[5]) > 1e9 for x in rows)
     v = re.findall(r"verify N=20000 mode=(\w+) steps=3: ranks agree (\w+); vs single GPU: rel_l2_pos ([0-9.e+-]+)", r.stderr)
     assert [(a, b) for a, b, _ in v] == [("plain", "yes"), ("overlap", "yes")] and all(float(x[2]) <= 1e-6 for x in v)
+    # preflight: every rank of the ipc attempt wrote its device, peer row and one IPC open of the next rank
+    pre = re.findall(r"# preflight rank (\d) of 2 transport=ipc device=0/1 pci=(\S+) can_access_peer=\[1\] ipc_export=0 ipc_open\(rank (\d)\)=0 ", r.stderr)
+    assert sorted((a, c) for a, _, c in pre) == [("0", "1"), ("1", "0")] and len({b for _, b, _ in pre}) == 1, r.stderr[-3000:]
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(ob.ORACLE_DIR, "_ref", "nbody-bench-ref")),
