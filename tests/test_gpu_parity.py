@@ -1839,6 +1839,36 @@ def test_bench_auto_lands_on_the_host_transport_when_rccl_and_direct_are_refused
     assert out["launch"]["seconds"] < out["launch"]["budget_s"]
 
 
+def test_bench_auto_survives_a_container_that_refuses_ipc_for_real():
+    """The same chain with nothing rehearsed: HSA_ENABLE_IPC_MODE_LEGACY=1 selects the IPC mode this pool's host driver does
+    not support, so hipIpcGetMemHandle fails with `invalid argument` -- a container refusing IPC.  Two ranks on this one
+    GPU: RCCL refuses the duplicate device, the direct exchange aborts at its first IPC export, the host transport needs
+    neither and delivers a verified headline.  The preflight of the failed attempts says WHY before anything aborted:
+    ipc_export_rc != 0 with the runtime's own error string (profiles/r06_legacy_ipc_2ranks.json is this run, kept)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "NB_BENCH_REHEARSE")}
+    env.update(OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="1")
+    r = subprocess.run([sys.executable, os.path.join(nb.ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--particles", "65536", "--extra-particles", "131072", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=nb.ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(lines[0])
+    attempts = out["launch"]["attempts"]
+    if len(attempts) == 2 and attempts[1]["child_rcs"] == [0, 0]:
+        pytest.skip("this box's driver serves the legacy IPC mode: the direct exchange came up")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert [(a["transport"], a.get("kind")) for a in attempts] == [("rccl", "bring_up_failed"), ("direct", "bring_up_failed"), ("host", None)]
+    for a in attempts[:2]:
+        ipc = [e for e in a["preflight"] if e.get("stage") == "ipc" and "ipc_export_rc" in e]
+        assert len(ipc) == 2 and all(e["ipc_export_rc"] != 0 and e["ipc_export_error"] and e["ipc_open_rc"] is None for e in ipc), a["preflight"]
+        assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "1" for e in a["preflight"] if e.get("stage") == "device")
+    assert "hipIpcGetMemHandle" in attempts[1]["stderr_tail"]          # the direct attempt died exactly where the preflight said it would
+    assert all("ipc_export_rc" not in e for e in attempts[2]["preflight"])      # the host transport never asked
+    assert out["transport"].startswith("host") and out["self_check"]["ok"] is True and out["value"] > 1e10
+    assert [(f["from"], f["to"]) for f in out["transport_fallback"]] == [("rccl", "direct"), ("direct", "host")]
+
+
 def test_host_transport_callback_that_raises_ends_the_process(golden, tmp_path):
     """A Python exception inside the caller-supplied all-gather must not escape into ctypes (it would be swallowed
     and the pipeline would step on stale peer slots): the thunk prints the traceback and leaves with exit code 5."""
