@@ -163,7 +163,9 @@ typedef struct Options {
     int modes[8];
     int n_modes;
     double wait_timeout_s, budget_s;
-    int selftest_die; /* --selftest-die R: that rank leaves with status 7 mid-run (the parent's reaping is what is tested) */
+    int selftest_die;  /* --selftest-die R: that rank leaves with status 7 mid-run (the parent's reaping is what is tested) */
+    int selftest_hang; /* --selftest-hang R: that rank never reaches the next barrier (the parent's budget is what is tested) */
+    bool budget_given;
 } Options;
 
 /* Every universe of the table, drawn up front from ONE srand(seed) stream in table order, like the reference
@@ -483,6 +485,8 @@ static int selftest_rank(const Options *o, NbRankPage *pg) {
     int bad = 0;
     nb_rank_barrier(pg, "selftest start");
     if (rank == o->selftest_die) _exit(7); /* the others are left waiting at the next barrier */
+    if (rank == o->selftest_hang)
+        for (;;) pause(); /* a collective that never completes: only the parent's budget ends this */
     for (int round = 0; round < 3; round++) {
         unsigned char id[NB_RANK_ID_BYTES];
         memset(id, 0, sizeof id);
@@ -606,7 +610,7 @@ static int run_ranks_once(const Options *o, double limit_s, int *timed_out) {
  * inside a process that did), every attempt inside its share of ONE budget.  A verification failure (status 5) is kept
  * apart from a bring-up failure: the chain goes on, but the run never reports success. */
 static int run_ranks(const Options *o) {
-    if (o->selftest_ranks) return run_ranks_once(o, 0.0, NULL);
+    if (o->selftest_ranks) return run_ranks_once(o, o->budget_given ? o->budget_s - 1.0 : 0.0, NULL);
     static const char *const NAME[3] = {"rccl", "ipc", "shm"};
     const double t0 = seconds_now();
     const int first = o->transport_auto ? 0 : o->transport_ipc ? 1 : o->transport_shm ? 2 : 0, last = o->transport_auto ? 2 : first;
@@ -689,7 +693,7 @@ int main(int argc, char **argv) {
     o.gpus = 1;
     o.wait_timeout_s = 180.0;
     o.budget_s = 480.0;
-    o.selftest_die = -1;
+    o.selftest_die = o.selftest_hang = -1;
     const char *modes = NULL;
 
     for (int a = 1; a < argc; a++) {
@@ -730,7 +734,7 @@ int main(int argc, char **argv) {
         } else if (!strcmp(arg, "--wait-timeout") && val) {
             o.wait_timeout_s = strtod(val, NULL), a++;
         } else if (!strcmp(arg, "--budget-s") && val) {
-            o.budget_s = strtod(val, NULL), a++;
+            o.budget_s = strtod(val, NULL), o.budget_given = true, a++;
         } else if (!strcmp(arg, "--force-sharded")) {
             o.force_sharded = true;
         } else if (!strcmp(arg, "--one-wave")) {
@@ -741,6 +745,8 @@ int main(int argc, char **argv) {
             o.selftest_ranks = true;
         } else if (!strcmp(arg, "--selftest-die") && val) {
             o.selftest_die = atoi(val), a++;
+        } else if (!strcmp(arg, "--selftest-hang") && val) {
+            o.selftest_hang = atoi(val), a++;
         } else {
             fprintf(stderr,
                     "usage: %s [--cpu|--gpu] [--n N]... [--steps K] [--warmup W] [--dt DT] [--galaxies G] [--seed S]"

@@ -298,6 +298,19 @@ def test_rank_page_a_dying_rank_ends_the_run_quickly():
     assert "selftest ok" not in r.stdout
 
 
+def test_rank_page_a_hung_rank_is_ended_by_the_parents_budget():
+    """--budget-s in the C harness: one rank never reaches the next barrier (a collective that never completes) while the page's
+    own wait timeout is far away; the parent -- which only waits and reaps -- ends exactly its children when the attempt has
+    used up its share, says so, and leaves non-zero: seconds, not the 60 s wait timeout."""
+    import time
+    nb.nbody_lib()
+    t0 = time.time()
+    r = subprocess.run([BENCH_EXE, "--gpus", "3", "--selftest-ranks", "--selftest-hang", "1", "--budget-s", "4", "--wait-timeout", "60"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 4 and 2.0 < time.time() - t0 < 15.0, (r.returncode, r.stderr)
+    assert "outlived its 3 s share of the budget; ending its 3 rank(s)" in r.stderr and "selftest ok" not in r.stdout
+
+
 def test_nbody_bench_rejects_a_captured_graph_over_the_host_transport():
     nb.nbody_lib()
     r = subprocess.run([BENCH_EXE, "--gpus", "2", "--transport", "shm", "--modes", "plain,graph"], capture_output=True, text=True, timeout=60)

@@ -1640,6 +1640,32 @@ def test_nbody_bench_c_falls_back_to_the_direct_exchange_in_fresh_ranks():
     assert sorted((a, c) for a, _, c in pre) == [("0", "1"), ("1", "0")] and len({b for _, b, _ in pre}) == 1, r.stderr[-3000:]
 
 
+def test_nbody_bench_c_walks_to_shm_when_the_driver_refuses_ipc():
+    """The C harness' whole chain, nothing rehearsed: with the IPC mode this pool's driver does not serve
+    (HSA_ENABLE_IPC_MODE_LEGACY=1: hipIpcGetMemHandle -> invalid argument) `nbody-bench --gpus 2` goes rccl (status 2: one device
+    for two ranks) -> ipc (status 134: abort() at the first IPC export, which the preflight line had already reported) -> shm,
+    whose table is verified against a single-GPU World like any other (profiles/r06_legacy_ipc_cbench.txt is this run, kept)."""
+    import re
+    if nb.device_count() >= 2:
+        pytest.skip("more than one GPU here: the RCCL attempt would succeed")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="1", OMP_NUM_THREADS="4")
+    r = subprocess.run([os.path.join(nb.LIB_DIR, "nbody-bench"), "--gpus", "2", "--n", "65536", "--steps", "5", "--warmup", "1", "--dt", "0.01"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=nb.ROOT)
+    marks = [l for l in r.stdout.splitlines() if l.startswith("# transport_fallback")]
+    if len(marks) == 1 and r.returncode == 0:
+        pytest.skip("this box's driver serves the legacy IPC mode: the direct exchange came up")
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert [m.split("(")[0].strip() for m in marks] == ["# transport_fallback rccl -> ipc", "# transport_fallback ipc -> shm"]
+    assert "bring_up_failed, status 2" in marks[0] and "bring_up_failed, status 134" in marks[1]
+    assert len(re.findall(r"# preflight rank \d of 2 transport=ipc .* ipc_export=[1-9]\d* \(", r.stderr)) == 2     # said why, before the abort
+    assert len(re.findall(r"# preflight rank \d of 2 transport=shm .* ipc=not probed", r.stderr)) == 2
+    rows = [l.split() for l in r.stdout.splitlines() if l.split() and l.split()[0] == "65536"]
+    assert [(x[1], x[2]) for x in rows] == [("2", "plain"), ("2", "overlap")] and all(float(x[5]) > 1e11 for x in rows)
+    v = re.findall(r"verify N=65536 mode=(\w+) steps=3: ranks agree (\w+); vs single GPU: rel_l2_pos ([0-9.e+-]+)", r.stderr)
+    assert [(a, b) for a, b, _ in v] == [("plain", "yes"), ("overlap", "yes")] and all(float(x[2]) <= 1e-6 for x in v)
+    assert "verification_failed" not in r.stdout + r.stderr
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(ob.ORACLE_DIR, "_ref", "nbody-bench-ref")),
                     reason="oracle/_ref/nbody-bench-ref not built")
 def test_reference_bench_c_runs_unchanged_on_our_library():

@@ -3,7 +3,7 @@
 # (tools/profile.sh, tools/profile_routes.sh, tools/profile_mid_n.sh).  usage: tools/collect_round.sh r05 [full]
 # "full" adds the frame-loop / graph-policy probes of round 2 (frozen since: the GUI they serve is out of scope).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 FULL=${2:-}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
