@@ -357,7 +357,8 @@ static void preflight_rank(const Options *o, NbRankPage *pg, int ndev) {
     const char *pci = strstr(info, "pci=");
     const int seen = nb_hip_preflight_peers(row, 16);
     for (int q = 0, at = 0; q < seen && q < 16 && at < (int)sizeof peers - 4; q++) at += snprintf(peers + at, sizeof peers - (size_t)at, "%s%d", q ? "," : "", row[q]);
-    char ipc[160] = "ipc=not probed (the shm transport needs none)";
+    char ipc[160];
+    snprintf(ipc, sizeof ipc, "ipc=not probed (%s)", P == 1 ? "one rank: no peer" : "the shm transport needs none");
     if (P > 1 && (o->transport_ipc || !o->transport_shm)) {
         /* one IPC open + close of the NEXT rank's exported word: handles travel through the page's exchange area */
         unsigned char *all = (unsigned char *)calloc((size_t)P, 72);
