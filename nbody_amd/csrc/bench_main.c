@@ -17,6 +17,10 @@
  *   --own-rng      draw the universes from MakeGalaxiesSeeded(seed + row) instead of libc rand()
  *   --repeats R    time the K-step call R times on the same world and report the fastest (default 1 = the
  *                  reference's single timed call; a row of a few hundred microseconds is at the mercy of one OS hiccup)
+ *   --cpu-best     one more column, INFORMATIONAL: the fastest CPU variant this host runs (libnbody_cpu_best.so: the same
+ *                  sim_cpu.c built AVX2+FMA / AVX-512, with sqrt + div or the rsqrt estimate + one Newton step; picked by a
+ *                  short calibration, named on stderr).  Not the reference's bits -- the CPU column stays the -mavx path that is
+ *                  (the reference's SIMD matrix: src/lib/CMakeLists.txt:24-33)
  * and more columns: interactions/s = N * mass_len * steps / time per backend, and for the GPU the share of the
  * fp32 roofline that is (14 flop per interaction, 157.3 TFLOP/s), then what the chip allows at THIS size:
  *   GPU floor = N * mass_len / R interactions/s       (R = the rate THIS run measures on THIS box at N = 100 000 before
@@ -146,13 +150,57 @@ static double measure_large_n_rate(void) {
     return (double)CALIBRATION_N * (double)m / busy;
 }
 
+/* libnbody_cpu_best.so (cpu_best.c): informational CPU variants of the stepper, never behind UpdateWorld_CPU */
+int nb_cpu_variant_count(void);
+const char *nb_cpu_variant_name(int i, int *supported, const char **what);
+int nb_cpu_variant_update(const char *isa, Particle *arr, uint32_t total_len, uint32_t mass_len, float dt, uint32_t n);
+
+/* seconds per step of `isa` on a partitioned copy of the world (sources first: what CreateWorld's partition yields) */
+static double time_cpu_variant(const char *isa, const Particle *ps, uint32_t n, float dt, uint32_t warmup, uint32_t steps, uint32_t repeats) {
+    World *w = CreateWorld(ps, n);
+    uint32_t got = 0;
+    const Particle *part = GetWorldParticles(w, &got);
+    Particle *arr = (Particle *)malloc((size_t)(n ? n : 1) * sizeof(Particle));
+    memcpy(arr, part, (size_t)n * sizeof(Particle));
+    uint32_t m = 0;
+    while (m < n && arr[m].mass > 0) m++;
+    DestroyWorld(w);
+    nb_cpu_variant_update(isa, arr, n, m, dt, warmup > 0 ? warmup : 1);
+    double best = 0.0;
+    for (uint32_t r = 0; r < repeats; r++) {
+        const double t0 = seconds_now();
+        nb_cpu_variant_update(isa, arr, n, m, dt, steps);
+        const double t1 = seconds_now();
+        if (r == 0 || t1 - t0 < best) best = t1 - t0;
+    }
+    free(arr);
+    return best / (double)steps;
+}
+
+/* the fastest variant this CPU runs, by a short calibration on a world of its own generator (libc's rand() stream stays
+ * the table's); NULL when the CPU runs none */
+static const char *pick_cpu_variant(void) {
+    Particle *ps = MakeGalaxiesSeeded(8000, 2, 0x243f6a8885a308d3ull);
+    const char *best = NULL;
+    double best_s = 0.0;
+    for (int i = 0; i < nb_cpu_variant_count(); i++) {
+        int ok = 0;
+        const char *what = NULL, *isa = nb_cpu_variant_name(i, &ok, &what);
+        if (!ok) continue;
+        const double s = time_cpu_variant(isa, ps, 8000, 0.01f, 2, 5, 2);
+        if (best == NULL || s < best_s) best = isa, best_s = s;
+    }
+    free(ps);
+    return best;
+}
+
 static const uint32_t REFERENCE_SIZES[] = {250, 500, 800, 1200, 2000, 4000, 10000, 20000, 50000, 100000};
 
 enum { MODE_PLAIN = 0, MODE_OVERLAP = 1, MODE_GRAPH = 2, MODE_COUNT = 3 };
 static const char *const MODE_NAME[MODE_COUNT] = {"plain", "overlap", "graph"};
 
 typedef struct Options {
-    bool use_cpu, use_gpu, own_rng, transport_shm, transport_ipc, transport_auto, force_sharded, selftest_ranks, verify_given, speedup, one_wave;
+    bool use_cpu, use_gpu, cpu_best, own_rng, transport_shm, transport_ipc, transport_auto, force_sharded, selftest_ranks, verify_given, speedup, one_wave;
     /* transport_shm: any host-callback transport (shm or ipc: both need the page's exchange area); transport_ipc: the direct one */
     uint32_t sizes[64];
     uint32_t n_sizes, steps, warmup, galaxies, repeats, verify_steps;
@@ -219,10 +267,17 @@ static int run_single(const Options *o) {
         fprintf(stderr, "nbody-bench: floor rate %.3e interactions/s (measured at N = %u on this box)\n", floor_rate, CALIBRATION_N);
     }
 
+    const char *best_isa = o->cpu_best ? pick_cpu_variant() : NULL;
+    if (o->cpu_best)
+        fprintf(stderr, "nbody-bench: --cpu-best column = %s (informational: not the reference's bits; the CPU column is the -mavx path that is)\n",
+                best_isa ? best_isa : "none of the variants runs on this CPU");
+
     printf("\t      N");
     if (o->use_cpu) printf("\t    CPU");
+    if (best_isa) printf("\t   CPU*");
     if (o->use_gpu) printf("\t    GPU");
     if (o->use_cpu) printf("\t  CPU int/s");
+    if (best_isa) printf("\t CPU* int/s");
     if (o->use_gpu) printf("\t  GPU int/s\t GPU %%peak\t  GPU us\tfloor us\t   %%floor");
     printf("\n");
 
@@ -242,10 +297,13 @@ static int run_single(const Options *o) {
             gpu_s = time_backend(w, UpdateWorld_GPU, o->dt, o->warmup, o->steps, o->repeats);
             DestroyWorld(w);
         }
+        const double best_s = best_isa ? time_cpu_variant(best_isa, ps, n, o->dt, o->warmup, o->steps, o->repeats) : 0.0;
         printf("\t%7u", n);
         if (o->use_cpu) printf("\t%7ld", (long)(cpu_s * 1e6));
+        if (best_isa) printf("\t%7ld", (long)(best_s * 1e6));
         if (o->use_gpu) printf("\t%7ld", (long)(gpu_s * 1e6));
         if (o->use_cpu) printf("\t%11.3e", pairs / cpu_s);
+        if (best_isa) printf("\t%11.3e", pairs / best_s);
         /* roofline column: 14 flop per interaction (reference op count, sim_cpu.c:169-188) against the
          * MI355X fp32 vector peak of 157.3 TFLOP/s -- the same convention as bench.py */
         if (o->use_gpu) {
@@ -722,6 +780,8 @@ int main(int argc, char **argv) {
             o.floor_rate = strtod(val, NULL), a++;
         } else if (!strcmp(arg, "--own-rng")) {
             o.own_rng = true;
+        } else if (!strcmp(arg, "--cpu-best")) {
+            o.cpu_best = true;
         } else if (!strcmp(arg, "--gpus") && val) {
             o.gpus = atoi(val), a++;
         } else if (!strcmp(arg, "--transport") && val && !strcmp(val, "auto")) {
@@ -751,7 +811,7 @@ int main(int argc, char **argv) {
         } else {
             fprintf(stderr,
                     "usage: %s [--cpu|--gpu] [--n N]... [--steps K] [--warmup W] [--dt DT] [--galaxies G] [--seed S]"
-                    " [--own-rng] [--repeats R] [--floor-rate INT_PER_S]\n"
+                    " [--own-rng] [--repeats R] [--cpu-best] [--floor-rate INT_PER_S]\n"
                     "       [--gpus P [--transport auto|rccl|ipc|shm] [--modes plain,overlap,graph] [--verify K] [--speedup] [--force-sharded] [--one-wave]"
                     " [--wait-timeout S] [--budget-s S] [--selftest-ranks]]\n",
                     argv[0]);

@@ -311,6 +311,23 @@ def test_rank_page_a_hung_rank_is_ended_by_the_parents_budget():
     assert "outlived its 3 s share of the budget; ending its 3 rank(s)" in r.stderr and "selftest ok" not in r.stdout
 
 
+def test_nbody_bench_cpu_best_column_is_extra_and_labelled():
+    """nbody-bench --cpu-best (SURVEY.md 8d's informational row in the C harness): one more column, named CPU*, from the
+    fastest CPU variant this host runs (said on stderr, with the reminder that it is not the reference's bits); without the
+    flag the table has exactly the reference's columns plus ours, as before."""
+    nb.nbody_lib()
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    plain = subprocess.run([BENCH_EXE, "--cpu", "--n", "1200", "--steps", "3"], env=env, capture_output=True, text=True, timeout=120)
+    assert plain.returncode == 0 and plain.stdout.splitlines()[0].split() == ["N", "CPU", "CPU", "int/s"] and "cpu-best" not in plain.stderr
+    r = subprocess.run([BENCH_EXE, "--cpu", "--cpu-best", "--n", "1200", "--steps", "3"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    head, row = [l.split() for l in r.stdout.splitlines()[:2]]
+    assert head == ["N", "CPU", "CPU*", "CPU", "int/s", "CPU*", "int/s"] and row[0] == "1200" and len(row) == 5
+    assert float(row[3]) > 0 and float(row[4]) > 0
+    names = [n for n, ok, _ in nb.cpu_variants() if ok]
+    assert "informational: not the reference's bits" in r.stderr and (any(f"column = {n} " in r.stderr for n in names) or not names)
+
+
 def test_nbody_bench_rejects_a_captured_graph_over_the_host_transport():
     nb.nbody_lib()
     r = subprocess.run([BENCH_EXE, "--gpus", "2", "--transport", "shm", "--modes", "plain,graph"], capture_output=True, text=True, timeout=60)
