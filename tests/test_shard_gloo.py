@@ -201,6 +201,27 @@ def test_bench_a_failed_self_check_is_not_a_bring_up_failure():
     assert out["value"] is None and out["error"].startswith("self_check failed") and out["verification_failed"][0]["transport"] == "rccl"
 
 
+def test_launch_budget_arithmetic_and_attempt_classes():
+    """nbody_amd/launch.py without processes: how the budget is carved (1/2, 1/2 of the rest, all of the rest, minus the
+    reserve kept for printing), and how a rank-0 line is classed: no line / a line without a value = bring-up failure; a
+    complete line whose self-check failed = VERIFICATION failure (the line comes back with the reason); ok otherwise."""
+    import json
+    from nbody_amd import launch
+    assert launch.TRANSPORT_CHAIN == ("rccl", "direct", "host")
+    assert launch.carve(480.0, 3) == 237.5 and launch.carve(480.0 - 237.5, 2) == 118.75 and launch.carve(100.0, 1) == 95.0
+    assert launch.carve(3.0, 2) == 0.0 and launch.carve(launch.PRINT_RESERVE_S + 2 * launch.MIN_ATTEMPT_S, 2) == launch.MIN_ATTEMPT_S
+    ok = {"metric": "m", "value": 1.0, "self_check": {"ranks_agree": True, "ok": True}}
+    assert launch.headline_of([json.dumps(ok)], 8, False) == (ok, None)
+    null = {"metric": "m", "value": None, "error": "leg 'headline' passed its deadline"}
+    assert launch.headline_of([json.dumps(null)], 8, False) == (None, "leg 'headline' passed its deadline")
+    for bad in ({"ranks_agree": False}, {"ranks_agree": True, "ok": False}):
+        line, why = launch.headline_of([json.dumps(dict(ok, self_check=bad))], 2, False)
+        assert line is not None and why.startswith("self_check failed")
+    line, why = launch.headline_of([json.dumps(dict(ok, self_check={"ranks_agree": False}))], 2, True)     # a dry run's check counts too
+    assert line is not None and why.startswith("self_check failed")
+    assert launch.headline_of([], 2, False) == (None, "rank 0 wrote no JSON line")
+
+
 def test_bench_help_lists_no_rehearsal_flag_and_the_rehearsals_live_with_the_tests():
     """the timed tool carries no test-only flag or branch; the hooks are observers registered by
     tests/bench_rehearsal.py when NB_BENCH_REHEARSE is set, and an unknown rehearsal is refused loudly."""
