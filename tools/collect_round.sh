@@ -53,15 +53,15 @@ python -m pytest tests/test_gpu_zz_perf.py -q -s -m gpu -k near_the_best > $O/${
 {
   echo "== tools/frame_probe.py: the reference GUI's frame loop through include/nbody.h (300 frames each), defaults =="
   python tools/frame_probe.py 6000 1000 100000
-  echo "== the same with round 1's behaviour: lazy read-back, timing events on every call, DMA upload =="
-  NB_HIP_READBACK=0 NB_HIP_TIMING=1 NB_HIP_ZERO_COPY_UPLOAD=0 python tools/frame_probe.py 6000 1000 100000
+  echo "== the same with round 1's behaviour: lazy read-back, timing events on every call, DMA upload (knobs set through nb_hip_tune and read back) =="
+  NB_FRAME_KNOBS="readback=0,timing=1,zero_copy_upload=0" python tools/frame_probe.py 6000 1000 100000
   echo "== one knob at a time, N = 6000 =="
-  NB_HIP_READBACK=0 python tools/frame_probe.py 6000
-  NB_HIP_TIMING=1 python tools/frame_probe.py 6000
-  NB_HIP_ZERO_COPY_UPLOAD=0 python tools/frame_probe.py 6000
-  NB_HIP_WAIT=spin python tools/frame_probe.py 6000
+  NB_FRAME_KNOBS="readback=0" python tools/frame_probe.py 6000
+  NB_FRAME_KNOBS="timing=1" python tools/frame_probe.py 6000
+  NB_FRAME_KNOBS="zero_copy_upload=0" python tools/frame_probe.py 6000
+  # (the wait policy NB_HIP_WAIT=spin|yield|block is read before the HIP context exists and only by TUNING=1 builds: not probed here)
   echo "== hipGraph chains in a frame loop: graph policy 0 (never) / 1 (always) / 2 (auto: 16+ steps, from the second use) =="
-  for g in 0 1 2; do NB_FRAME_UPDATES=2,8,16,32 NB_HIP_GRAPH=$g NB_HIP_READBACK=0 python tools/frame_probe.py 6000 | sed "s/^/[graph knob $g] /"; done
+  for g in 0 1 2; do NB_FRAME_UPDATES=2,8,16,32 NB_HIP_GRAPH=$g NB_FRAME_KNOBS="readback=0" python tools/frame_probe.py 6000 | sed "s/^/[graph knob $g] /"; done
 } > $O/${TAG}_frame_loop_latency.txt 2>&1; echo "frame rc=$?"
 python tools/odd_chain_probe.py > $O/${TAG}_odd_chain_probe.txt 2>&1; echo "odd rc=$?"
 python tools/first_call_probe.py > $O/${TAG}_first_call_probe.txt 2>&1; echo "first-call rc=$?"
