@@ -3,8 +3,9 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one process per GPU
 through torch.distributed.run.  One JSON line on rank 0.  `python bench.py --gpus N` started BARE works too: the process
-that is started never touches the GPU -- it is a supervisor over fresh rank processes (supervise()),
-which is also what every rank process is under torch.distributed.run.
+that is started never touches the GPU -- it is a supervisor over fresh rank processes (nbody_amd/launch.py, DESIGN.md
+section 4), which is also what every rank process is under torch.distributed.run.  The whole run lives inside ONE budget
+(--budget-s, default 480 s: under the 600 s a driver allows the command) and always prints its line.
 
 Workload (BASELINE.json metric): srand(11037); MakeGalaxies(2^20, 2) -- the reference bench's universe
 (src/bench.c:42,53) at the size the metric is quoted on -- partitioned by CreateWorld, dt = 0.01.  A "step" is one force +
@@ -13,8 +14,9 @@ reference kernels evaluate, particle_cs.glsl:30,35).  K steps run as ONE Perform
 harness' update(w, dt, 100) (bench.c:30-33); particles are resident in HBM before the timed region (SetSimulationData is
 outside it).
 
-N = 1: the CPU baseline runs FIRST (the reference's own UpdateWorld_CPU, compiled where it lies, and the product's on the
-same World and thread count), then the GPU legs back to back: headline K steps -- from here on the line is in hand and
+N = 1: the CPU baseline runs FIRST (the reference's own UpdateWorld_CPU, compiled where it lies, the product's on the
+same World and thread count, and -- informational -- the fastest CPU variant the host runs: cpu_baseline.best_cpu), then the
+GPU legs back to back: headline K steps -- from here on the line is in hand and
 every later leg runs under a C-level last-gasp handler --, the clock probe, the headline's parity stamp, two repeats of
 the same K steps (run-to-run spread), the same K steps with the clock sampler beside them (roofline.held_clock_ghz,
 cycles_per_wave_interaction), the LDS-tile route (roofline.alt_lds), and `extra_configs`: BASELINE.json's other
@@ -24,17 +26,20 @@ product's nbody-bench --cpu, no GPU) -- and the per-rank shard steps S2 / S4 / S
 8-way sharded run costs, measured on this one GPU (the compute half of the 1/2/4/8 curve).
 
 N > 1: strong scaling -- the same 2^20 particles, N/P receivers per GPU, all-gather of source positions per step over RCCL
-inside the library.  `--transport auto` (default): an RCCL attempt whose ranks do not all deliver a complete headline is
-followed by a FRESH set of rank processes over the direct device-to-device exchange; the line then carries
-"transport_fallback".  The rendezvous, the barriers and the reductions of the timings go over a stdlib Unix-socket hub
+inside the library.  `--transport auto` (default) = rccl -> direct -> host: an attempt that does not deliver a verified
+headline (a rank that leaves during bring-up, a time-out, a failed self-check) is followed by a FRESH set of rank processes
+over the next transport; the line carries one "transport_fallback" entry per step, and a failed self-check stays on it as
+"verification_failed" (exit code 5 whatever follows).  Before the first contact every rank writes its "preflight" record
+(PCI address, peer-access row, one IPC open of the next rank's word, RCCL bring-up timings).  The rendezvous, the barriers and the reductions of the timings go over a stdlib Unix-socket hub
 between the ranks (nbody_amd/ranklink.py): torch is NOT imported, so the HIP runtime and the librccl the data path binds
 are /opt/rocm's -- the stack every single-GPU test runs on (`--rendezvous gloo` keeps the round-3 route).  The JSON dict
 is COMPLETE after the headline leg and the self-check (mandatory for every N > 1 headline: all ranks agree and match a
 single-GPU run; what the RCCL communicator itself reports; per-step kernel / all-gather times); every later leg
 (`extra_configs`: overlapped step, the chain captured as a hipGraph, BASELINE.json's config 5 at N = 2^22 plain and
-overlapped, the direct exchange with its own self-check) runs under a host-side deadline: if one stalls, rank 0 writes
-the line with what is in hand plus "extras_aborted": "<leg>" and every rank leaves with exit code 4 -- a fresh exit,
-never a re-exec.
+overlapped, the direct exchange with its own self-check) runs under a host-side deadline -- as does the headline leg itself,
+inside the attempt's share of the budget: if one stalls, rank 0 writes the line with what is in hand plus "extras_aborted":
+"<leg>" (or, with no headline yet, value null and why) and every rank leaves with exit code 4 -- a fresh exit, never a
+re-exec.  Failure rehearsals are not in this file: tests/bench_rehearsal.py registers observers when NB_BENCH_REHEARSE is set.
 
 `runtime` in the JSON line says which HIP runtime and librccl the run bound.
 
