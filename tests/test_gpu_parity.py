@@ -1996,6 +1996,23 @@ def test_single_gpu_bench_line_survives_a_leg_that_aborts(leg):
     assert ("parity" in out) == (leg != "clock probe")      # legs that finished before the abort are on the line
 
 
+def test_single_gpu_bench_skips_the_legs_its_budget_no_longer_holds():
+    """--budget-s bounds the single-GPU run too: with a budget that covers the headline and little else, the optional legs
+    that need more than what is left are LISTED (legs_skipped_for_budget) instead of started, the headline is unaffected, and
+    the run reports success -- a slow box costs legs, never the line."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(nb.ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--budget-s", "14"],
+                       capture_output=True, text=True, timeout=600, cwd=nb.ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["value"] > 1e12 and out["roofline"]["frac"] > 0.3 and "extras_aborted" not in out
+    skipped = out["legs_skipped_for_budget"]
+    assert "extra_configs C2/C3/N2/C1" in skipped and "extra_configs S2/S4/S8/C5S8" in skipped
+    assert out.get("extra_configs", []) == []
+
+
 @pytest.mark.parametrize("ranks", [2, 3, 8])
 def test_bench_shard_leg_times_every_ranks_step_and_stamps_it(ranks):
     """bench.py's S-legs (extra_configs S2 / S4 / S8 / C5S8) at a small size: all shards of one world in this process, every
