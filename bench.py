@@ -960,6 +960,18 @@ def single_gpu_configs(nb, stamp=True):
     entry["later_calls"] = dict(rate(n, m, min(later)), note="fastest of 3 further 100-step calls (cached hipGraph replays)")
     if stamp:
         entry["parity"] = parity_stamp(sim, m)
+    # BASELINE.json words config 2 as "single LDS-tiled force+integrate kernel": the same calls through the LDS-tile source route
+    # (variant = 0; bit-identical results, the route the north star names) beside the default scalar-cache route above
+    sim.configure(variant=0)
+    sim.update(100, DT)
+    lds = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        sim.update(100, DT)
+        lds.append((time.perf_counter() - t0) / 100)
+    entry["lds_route"] = dict(rate(n, m, min(lds)), kernel=sim.launch_shape(), note="fastest of 3 100-step calls through the LDS-tile route")
+    if stamp:
+        entry["lds_route"]["parity"] = parity_stamp(sim, m)
     sim.close()
     out.append(entry)
 
