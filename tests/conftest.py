@@ -22,12 +22,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+GPU_FILE_ORDER = ["test_gpu_parity.py", "test_gpu_chains.py", "test_gpu_sharded.py", "test_gpu_harness.py", "test_gpu_zz_perf.py"]
+
+
 def pytest_collection_modifyitems(config, items):
-    """Wall-clock assertions run after every correctness row, whatever the files are called: the driver runs the GPU
-    suite with -x, and a slow box must not leave oracle / fixture / transport tests untested."""
-    perf = [it for it in items if it.fspath.basename == "test_gpu_zz_perf.py"]
-    if perf:
-        items[:] = [it for it in items if it.fspath.basename != "test_gpu_zz_perf.py"] + perf
+    """The GPU files run in a stated order whatever they are called: oracle / fixture parity first, then chains, the sharded
+    pipeline, the harnesses -- and the wall-clock assertions (test_gpu_zz_perf.py) LAST: the driver runs the GPU suite with
+    -x, and a slow box must not leave correctness rows untested."""
+    def rank(item):
+        name = item.fspath.basename
+        return GPU_FILE_ORDER.index(name) + 1 if name in GPU_FILE_ORDER else 0
+    items.sort(key=rank)      # stable: everything else keeps its collection order, ahead of the GPU files
 
 
 @pytest.fixture(scope="session")

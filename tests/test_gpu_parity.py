@@ -10,81 +10,20 @@ Ten steps at dt = 0.01: relative L2 over all positions <= 1e-6 AND, the sharp on
 |(pos - pos0)_gpu - (pos - pos0)_ref| / |(pos - pos0)_ref| <= 1e-4 (rel_displacement; the reference's own sequential
 and AVX orders differ by 8.7e-7 there).  Nothing is asserted on 100-step trajectories (chaotic).  Integer-like facts (partition order, mass, radius, pass-through) are bit-exact.
 """
-import ctypes as C
-import os
-import subprocess
-import sys
-import time
+import ctypes as C  # noqa: F401
+import os  # noqa: F401
+import subprocess  # noqa: F401
+import sys  # noqa: F401
+import time  # noqa: F401
 
-import numpy as np
+import numpy as np  # noqa: F401
 import pytest
 
-import nbody_amd as nb
-import oracle_binding as ob
+import nbody_amd as nb  # noqa: F401
+import oracle_binding as ob  # noqa: F401
+from gpu_common import *  # noqa: F401,F403  -- helpers shared by the GPU test files (tests/gpu_common.py)
 
 pytestmark = pytest.mark.gpu
-
-SHAPES = [(0, 0), (1, 1), (1, 16), (2, 4), (2, 1), (1, 4), (2, 16), (2, 8)]   # K = 4 / W = 2 exist in TUNING=1 builds only
-
-
-def acc_bound(acc64, mag):
-    return 1e-4 * np.abs(acc64) + 1e-6 * mag
-
-
-def check_one_step(got, part, m, dt, want=None):
-    """got = device state one step after `part`; checks acc against float64 and vel/pos against the AVX path."""
-    acc64, mag = ob.acc_f64(part, m)
-    bound = acc_bound(acc64, mag)
-    err = np.abs(got[:, 4:6].astype(np.float64) - acc64)
-    assert np.all(err <= bound), f"acc outside tolerance: worst ratio {np.max(err / bound):.3f}"
-    # the integrator is exact fp32 arithmetic on the device's own acc, with the reference's roundings
-    # (vel += acc*dt; pos += vel*dt; mul then add, reference sim_cpu.c:191-193): bit-exact
-    v = part[:, 2:4] + got[:, 4:6] * np.float32(dt)
-    p = part[:, 0:2] + v * np.float32(dt)
-    assert np.array_equal(got[:, 2:4], v), "velocity is not vel + acc*dt in fp32"
-    assert np.array_equal(got[:, 0:2], p), "position is not pos + vel*dt in fp32"
-    # against the reference AVX path: both sit within the same bound of the float64 sum
-    if want is None:
-        want = ob.step(part, m, dt, 1)
-    e_ref = np.abs(want[:, 4:6].astype(np.float64) - acc64)
-    assert np.all(np.abs(got[:, 4:6].astype(np.float64) - want[:, 4:6]) <= bound + e_ref)
-    assert np.array_equal(got[:, 6:8], part[:, 6:8]), "mass / radius must pass through untouched"
-
-
-def run(part, m, n, dt, **knobs):
-    sim = nb.SimPipeline(part.shape[0], m)
-    sim.configure(**knobs)
-    sim.set_data(part)
-    sim.update(n, dt)
-    out = sim.get_data()
-    sim.close()
-    return out
-
-
-def rel_displacement(got, want, start):
-    """Multi-step parity metric relative to what the steps MOVED, not to where the particles are:
-    |(pos - pos0)_gpu - (pos - pos0)_ref| / |(pos - pos0)_ref| over all particles.  Relative to the positions
-    themselves (1e4..1e6) ten steps at dt = 0.01 are a 1e-4 perturbation, so "rel L2 of pos <= 1e-6" would still pass
-    with gravity switched off (5.5e-4 on this metric's scale); the reference's own sequential and AVX summation orders
-    differ by 8.7e-7 here (reference world.c:99-110 semantics, ten calls of the step)."""
-    p0 = start[:, 0:2].astype(np.float64)
-    dg = got[:, 0:2].astype(np.float64) - p0
-    dw = want[:, 0:2].astype(np.float64) - p0
-    return float(np.linalg.norm(dg - dw) / np.linalg.norm(dw))
-
-
-DISPLACEMENT_TOL = 1e-4   # stated multi-step tolerance (README / DESIGN.md section 5); observed ~1e-6
-
-
-def synth(n, frac_massive=0.5, seed=0, extent=1.0e4):
-    rng = np.random.default_rng(seed)
-    a = np.zeros((n, 8), dtype=np.float32)
-    a[:, 0:2] = rng.standard_normal((n, 2)) * extent
-    a[:, 2:4] = rng.standard_normal((n, 2)) * 10
-    massive = rng.random(n) < frac_massive
-    a[:, 7] = np.where(massive, 1.5 + 8 * rng.random(n), 0.5)
-    a[:, 6] = np.where(massive, 41.9 * a[:, 7] ** 3, 0.0)
-    return ob.partition(a)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -256,389 +195,6 @@ def test_eager_read_back_through_the_seam_with_a_foreign_buffer(golden):
     assert sim.get_data().tobytes() == run(part, m, 3, 0.01).tobytes()
     nb.hip_lib().nb_hip_note_host_array(sim._h, None, 0)
     sim.close()
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# step chains: hipGraph vs plain launches, phases, dt patching
-# ---------------------------------------------------------------------------------------------------------------
-
-def avx_steps(part, m, schedule):
-    """The reference AVX stepper (bit-exact restatement, world.c:99-110 semantics) over a schedule of (steps, dt) calls."""
-    state = part
-    for n, dt in schedule:
-        state = ob.step(state, m, dt, n)
-    return state
-
-
-def f64_steps(part, m, schedule):
-    """The float64 stepper (terms, sums, state and integrator in double: oracle orc_step_f64) over the same schedule."""
-    state = part
-    for n, dt in schedule:
-        state = ob.step(state, m, dt, n, kind="f64")
-    return state
-
-
-SEGMENT_STEPS = 10   # the stated multi-step tolerance is defined over at most ten steps from an identical state
-
-
-def assert_anchored(got, part, m, schedule, label="", **knobs):
-    """Multi-step anchor of a GPU trajectory of ANY length against the reference CPU path (world.c:99-110,
-    sim_cpu.c:156-194), with float64 as the tie-breaker ("closer to fp64 than the AVX path is, is
-    acceptable") -- no looser bound for long chains and no part of a schedule left out.
-
-    Up to ten steps: `got` itself against the AVX stepper at the stated tolerance (1e-4 of what the steps moved), and no
-    further from the float64 trajectory than 1.5 x the AVX stepper's own distance from it.
-
-    Longer schedules: the N-body system is chaotic (a close encounter in the 333-particle fixture multiplies any
-    difference by ~4 000 between steps 130 and 343: the reference's own AVX build ends 1.8e-3 from the float64 trajectory
-    there, this engine 2.9e-3), so end-to-end distances of two fp32 implementations are O(1) multiples of each other by
-    chance and cannot carry a bound.  Instead the WHOLE schedule is re-walked on a second pipeline in calls of at most ten
-    steps (plain launches; `knobs` select the launch shape the trajectory under test is bit-equal to), and every segment
-    is anchored FROM THE GPU'S OWN STATE at its start: GPU segment vs AVX segment at 1e-4, GPU-f64 <= 1.5 x AVX-f64.  The
-    re-walk must end on `got` bit for bit, which ties the checked segments to the trajectory under test.  The end-to-end
-    distances are printed for the record (pytest -rP)."""
-    total = sum(n for n, _ in schedule)
-
-    def check_segment(end_state, start_state, n, dt, what):
-        avx = ob.step(start_state, m, dt, n)
-        f64 = ob.step(start_state, m, dt, n, kind="f64")
-        d_pair = rel_displacement(end_state, avx, start_state)
-        d_gpu, d_avx = rel_displacement(end_state, f64, start_state), rel_displacement(avx, f64, start_state)
-        assert d_pair <= DISPLACEMENT_TOL, (label, what, d_pair)
-        assert d_gpu <= 1.5 * d_avx + 1e-9, (label, what, d_gpu, d_avx)
-        assert np.array_equal(end_state[:, 6:8], avx[:, 6:8])
-        return d_pair, d_gpu, d_avx
-
-    if total <= SEGMENT_STEPS and len(schedule) == 1:
-        d = check_segment(got, part, schedule[0][0], schedule[0][1], f"{total} steps")
-        print(f"[anchor] {label} {total} steps: gpu-avx {d[0]:.3e}  gpu-f64 {d[1]:.3e}  avx-f64 {d[2]:.3e}")
-        return
-    walker = nb.SimPipeline(part.shape[0], m)
-    walker.configure(**dict(dict(graph=0), **knobs))
-    walker.set_data(part)
-    state, done, worst = part, 0, (0.0, 0.0, 0.0)
-    for n, dt in schedule:
-        left = n
-        while left > 0:
-            k = min(left, SEGMENT_STEPS)
-            walker.update(k, dt)
-            nxt = walker.get_data()
-            d = check_segment(nxt, state, k, dt, f"steps {done}..{done + k} of {total}")
-            worst = tuple(max(a, b) for a, b in zip(worst, d))
-            state, done, left = nxt, done + k, left - k
-    walker.close()
-    assert state.tobytes() == got.tobytes(), (label, "the re-walked schedule does not end on the trajectory under test")
-    f64, avx = f64_steps(part, m, schedule), avx_steps(part, m, schedule)
-    print(f"[anchor] {label} {total} steps in segments of <= {SEGMENT_STEPS}: worst segment gpu-avx {worst[0]:.3e}  gpu-f64 {worst[1]:.3e}  "
-          f"avx-f64 {worst[2]:.3e}; end to end (chaotic, not asserted): gpu-f64 {rel_displacement(got, f64, part):.3e}  "
-          f"avx-f64 {rel_displacement(avx, f64, part):.3e}  gpu-avx {rel_displacement(got, avx, part):.3e}")
-
-
-@pytest.mark.parametrize("n_steps", [1, 2, 3, 7, 64, 65, 130])
-def test_graph_chain_equals_plain_launches(golden, n_steps):
-    part, m = ob.partition(golden("ic_333.bin"))
-    a = run(part, m, n_steps, 0.01, graph=1)
-    b = run(part, m, n_steps, 0.01, graph=0)
-    assert a.tobytes() == b.tobytes()
-    # ... and both are the reference's trajectory, not merely each other's
-    assert_anchored(a, part, m, [(n_steps, 0.01)], "graph chain")
-
-
-@pytest.mark.parametrize("graph", [1, 2])
-def test_split_calls_and_odd_phases(golden, graph):
-    # graph = 2 (the default) on a small world: one canonical 32-step chain, prebuilt at set_data, replayed by calls of
-    # 16+ steps (plain launches to reach phase 0 and for the remainder); shorter calls are plain launches
-    part, m = ob.partition(golden("ic_333.bin"))
-    calls = (3, 3, 1, 5, 3, 3, 17, 17, 16, 17, 17, 40, 33, 71, 32, 1, 64)   # lengths reused on the other ping-pong phase
-    want = run(part, m, sum(calls), 0.01, graph=0)
-    sim = nb.SimPipeline(333, m)
-    sim.configure(graph=graph)
-    sim.set_data(part)
-    for n in calls:
-        sim.update(n, 0.01)
-    got = sim.get_data()
-    stats = sim.graph_stats()
-    sim.close()
-    assert got.tobytes() == want.tobytes()
-    assert stats["cached"] == (8 if graph == 1 else 1)   # always: one per (length, phase), capped at 8; auto: the canonical one
-    assert stats["dt_uploads"] == 1
-    # the WHOLE 343-step schedule, call by call, against the reference stepper with float64 as the tie-break -- and its
-    # first calls (7 steps) at the stated tolerance
-    assert_anchored(got, part, m, [(n, 0.01) for n in calls], f"split calls graph={graph}")
-    head = nb.SimPipeline(333, m)
-    head.configure(graph=graph)
-    head.set_data(part)
-    for n in calls[:3]:
-        head.update(n, 0.01)
-    early = head.get_data()
-    head.close()
-    assert_anchored(early, part, m, [(n, 0.01) for n in calls[:3]], "split calls, first three")
-
-
-@pytest.mark.parametrize("graph", [1, 2])
-def test_dt_change_patches_the_cached_chain(golden, graph):
-    part, m = ob.partition(golden("ic_333.bin"))
-    n = 4 if graph == 1 else 40  # auto mode: 40 = one replay of the canonical 32-step chain + 8 plain launches
-    sim = nb.SimPipeline(333, m)
-    sim.configure(graph=graph)
-    sim.set_data(part)
-    sim.update(n, 0.01)
-    sim.update(n, 0.005)         # same n, dt halved: a 4-byte write to device memory, the cached chain is untouched
-    sim.update(n, 0.01)
-    sim.update(n, 0.0025)
-    got = sim.get_data()
-    assert sim.graph_stats() == {"cached": 1, "dt_uploads": 4}
-    sim.close()
-    ref = nb.SimPipeline(333, m)
-    ref.configure(graph=0)
-    ref.set_data(part)
-    for dt in (0.01, 0.005, 0.01, 0.0025):
-        ref.update(n, dt)
-    want = ref.get_data()
-    ref.close()
-    assert got.tobytes() == want.tobytes()
-    # the dt the chain read from device memory is the dt the reference path was given, call by call
-    assert_anchored(got, part, m, [(n, dt) for dt in (0.01, 0.005, 0.01, 0.0025)], f"dt change graph={graph}")
-    wrong = avx_steps(part, m, [(n, 0.01)] * 4)          # had the chain kept its first dt, it would be here
-    assert rel_displacement(got, wrong, part) > 0.1
-
-
-def test_long_runs_replay_the_canonical_chain_exactly(golden):
-    """5 000 steps in auto mode (the prebuilt 32-step chain replayed 156 times + 8 plain launches) = 50 calls of 100
-    steps = 5 000 plain launches, bit for bit; the pipeline keeps one cached chain throughout."""
-    part, m = ob.partition(golden("ic_1024.bin"))
-    want = run(part, m, 5000, 0.001, graph=0)
-    assert run(part, m, 5000, 0.001).tobytes() == want.tobytes()
-    sim = nb.SimPipeline(1024, m)
-    sim.set_data(part)
-    for _ in range(50):
-        sim.update(100, 0.001)
-    stats = sim.graph_stats()
-    got = sim.get_data()
-    sim.close()
-    assert got.tobytes() == want.tobytes() and stats == {"cached": 1, "dt_uploads": 1}
-    assert np.all(np.isfinite(got))
-
-
-def test_set_data_again_restarts_from_the_new_state(golden):
-    part, m = ob.partition(golden("ic_333.bin"))
-    sim = nb.SimPipeline(333, m)
-    sim.set_data(part)
-    sim.update(3, 0.01)
-    sim.set_data(part)
-    sim.update(2, 0.01)
-    got = sim.get_data()
-    sim.close()
-    assert got.tobytes() == run(part, m, 2, 0.01).tobytes()
-    want = avx_steps(part, m, [(2, 0.01)])
-    assert rel_displacement(got, want, part) <= DISPLACEMENT_TOL
-
-
-def test_async_steps_then_sync(golden):
-    part, m = ob.partition(golden("ic_333.bin"))
-    sim = nb.SimPipeline(333, m)
-    sim.set_data(part)
-    sim.step_async(2, 0.01)
-    sim.step_async(3, 0.01)
-    sim.sync()
-    ms, launches = sim.last_step_ms()
-    got = sim.get_data()
-    sim.close()
-    assert launches == 3 and ms > 0
-    assert got.tobytes() == run(part, m, 5, 0.01).tobytes()
-    assert rel_displacement(got, avx_steps(part, m, [(5, 0.01)]), part) <= DISPLACEMENT_TOL
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# the one-workgroup chain (knob "fused_chain"): a whole n-step call inside ONE launch, positions in LDS
-# ---------------------------------------------------------------------------------------------------------------
-
-def matched_shape(n):
-    """The per-step launch shape whose summation order the one-workgroup chain reproduces."""
-    tiles = 1 if n <= 128 else 2 if n <= 256 else 4
-    return dict(k=2, w=16 // tiles, split=1, unit=8)
-
-
-@pytest.mark.parametrize("n_steps", [2, 3, 7, 64, 65, 130])
-@pytest.mark.parametrize("n", [100, 250, 333, 512])
-def test_fused_chain_equals_plain_launches(n, n_steps):
-    """n steps inside one launch == n per-step launches of the matching shape (k = 2, w = 16 / tiles, split = 1,
-    unit = 8), bit for bit: same interaction statements, same source slices, same reduction order, same integrator
-    roundings; only the kernel boundaries are gone."""
-    part, m = bench_universe(n)[1:] if n >= 200 else synth(n, 0.5, seed=n)   # MakeGalaxies needs 100 per galaxy
-    sim = nb.SimPipeline(n, m)
-    sim.configure(fused_chain=1)
-    sim.set_data(part)
-    sim.update(n_steps, 0.01)
-    assert sim.fused_steps() == n_steps and sim.last_step_ms()[1] == 1          # ONE launch
-    shape = sim.launch_shape()
-    assert {key: shape[key] for key in ("k", "w", "split", "unit")} == matched_shape(n) and shape["workgroups"] == 1
-    got = sim.get_data()
-    sim.close()
-    want = run(part, m, n_steps, 0.01, fused_chain=0, graph=0, **matched_shape(n))
-    assert got.tobytes() == want.tobytes()
-    assert got.tobytes() == run(part, m, n_steps, 0.01, fused_chain=0, graph=1, **matched_shape(n)).tobytes()
-    assert_anchored(got, part, m, [(n_steps, 0.01)], f"fused chain N={n}", fused_chain=0, **matched_shape(n))
-
-
-def test_fused_chain_auto_policy_and_split_calls():
-    """Auto: calls of 2+ steps on worlds with N <= 256 and N x M <= 3.6e4 (the reference harness' N = 250 row) run fused, single steps
-    and larger worlds do not; a new dt reaches the chain through device memory like any other step; and a sequence of
-    fused calls equals one long fused call."""
-    _, part, m = bench_universe(250)
-    sim = nb.SimPipeline(250, m)
-    sim.set_data(part)
-    sim.update(1, 0.01)
-    assert sim.fused_steps() == 0                       # one step: nothing to fuse
-    sim.set_data(part)
-    for n_steps, dt in ((3, 0.01), (2, 0.005), (100, 0.01), (5, 0.0025)):
-        sim.update(n_steps, dt)
-        assert sim.fused_steps() == n_steps
-    got = sim.get_data()
-    assert sim.graph_stats()["cached"] == 0 and sim.graph_stats()["dt_uploads"] == 4   # no hipGraph is ever built for it
-    sim.close()
-    ref = nb.SimPipeline(250, m)
-    ref.configure(fused_chain=0, graph=0, **matched_shape(250))
-    ref.set_data(part)
-    for n_steps, dt in ((3, 0.01), (2, 0.005), (100, 0.01), (5, 0.0025)):
-        ref.update(n_steps, dt)
-        assert ref.fused_steps() == 0
-    want = ref.get_data()
-    ref.close()
-    assert got.tobytes() == want.tobytes()
-    # explicit shape knobs ask for the per-step kernel; larger worlds stay on it
-    assert run(part, m, 4, 0.01, k=1, w=16).tobytes() == run(part, m, 4, 0.01, k=1, w=16, fused_chain=0).tobytes()
-    _, part333, m333 = bench_universe(333)
-    big = nb.SimPipeline(333, m333)
-    big.set_data(part333)
-    big.update(10, 0.01)
-    assert big.fused_steps() == 0
-    big.close()
-
-
-def test_fused_chain_against_the_reference_path():
-    """The fused chain is the default for the reference harness' smallest world: one step from the bench's N = 250
-    universe against float64 (through two fused steps with dt = 0: the second step's acc is the force at the unmoved
-    state), and ten steps against the reference's AVX stepper on the displacement metric."""
-    _, part, m = bench_universe(250)
-    still = run(part, m, 2, 0.0)                        # dt = 0: nothing moves, acc = the force field, twice
-    acc64, mag = ob.acc_f64(part, m)
-    assert np.all(np.abs(still[:, 4:6].astype(np.float64) - acc64) <= acc_bound(acc64, mag))
-    assert np.array_equal(still[:, 0:4], part[:, 0:4]) and np.array_equal(still[:, 6:8], part[:, 6:8])
-    want = ob.step(part, m, 0.01, 10, kind="avx")
-    sim = nb.SimPipeline(250, m)
-    sim.set_data(part)
-    sim.update(10, 0.01)
-    assert sim.fused_steps() == 10
-    got = sim.get_data()
-    sim.close()
-    assert rel_l2_pos(got, want) <= 1e-6 and rel_displacement(got, want, part) <= DISPLACEMENT_TOL
-    # the World surface takes the same path (nbody-bench's 100-step call)
-    ic = nb.make_galaxies(250, 2, seed=11037)
-    w = nb.World(ic)
-    w.update_gpu(0.01, 10)
-    assert w.particles().tobytes() == got.tobytes()
-    w.close()
-
-
-@pytest.mark.parametrize("n,frac", [(1, 1.0), (2, 0.5), (64, 1.0), (65, 0.3), (129, 0.02), (130, 1.0), (257, 0.5), (300, 0.0),
-                                    (511, 1.0), (512, 0.6)])
-def test_fused_chain_ragged_worlds(n, frac):
-    part, m = synth(n, frac, seed=7 * n)
-    got = run(part, m, 3, 0.02, fused_chain=1)
-    want = run(part, m, 3, 0.02, fused_chain=0, graph=0, **matched_shape(n))
-    assert got.tobytes() == want.tobytes()
-    if m:
-        check_one_step(run(part, m, 1, 0.02, fused_chain=0, **matched_shape(n)), part, m, 0.02)
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# lane-split launches (knob "lanes"): several source slices per receiver inside one wave, sources staged in LDS
-# ---------------------------------------------------------------------------------------------------------------
-
-@pytest.mark.parametrize("lanes,w", [(2, 4), (2, 16), (4, 8), (4, 16), (8, 8), (8, 16)])
-def test_lane_split_shapes_against_float64(golden, lanes, w):
-    """Every lane-split instantiation against float64 and the integrator's exact roundings, at the fixtures and at
-    source counts around every granule / group / slice boundary (a slice is a whole number of 8-source granules, walked in
-    groups of four; trailing slices are empty), with receivers that do not fill the last workgroup."""
-    for n in (4096, 333):
-        part, m = ob.partition(golden(f"ic_{n}.bin"))
-        sim = nb.SimPipeline(n, m)
-        sim.configure(lanes=lanes, w=w)
-        sim.set_data(part)
-        sim.update(1, 0.01)
-        shape = sim.launch_shape()
-        got = sim.get_data()
-        sim.close()
-        assert (shape["lanes"], shape["w"], shape["k"], shape["split"]) == (lanes, w, 1, 1)
-        assert shape["workgroups"] == -(-n // (64 // lanes))
-        check_one_step(got, part, m, 0.01)
-    for m_want in (1, 3, 4, 5, 7, 8, 9, 31, 32, 33, 63, 64, 65, 100, 255, 256, 257, 511, 513, 1000, 1031, 2049):
-        n = m_want + 37
-        part, m = synth(n, 1.0, seed=50 + m_want)
-        part[m_want:, 6] = 0.0
-        part, m = ob.partition(part)
-        assert m == m_want
-        got = run(part, m, 1, 0.01, lanes=lanes, w=w)
-        check_one_step(got, part, m, 0.01)
-    # graph replay == plain launches, and a second step reads the first one's output
-    part, m = ob.partition(golden("ic_1024.bin"))
-    assert run(part, m, 5, 0.01, lanes=lanes, w=w, graph=1).tobytes() == run(part, m, 5, 0.01, lanes=lanes, w=w, graph=0).tobytes()
-
-
-def test_lane_split_auto_policy_and_multi_step_parity():
-    """All knobs on auto: latency-bound unsharded steps (N x M <= 9e6) run lane-split -- ONE kernel per step where the
-    classic model would split the sources and add a finish kernel; larger worlds, sharded pipelines, an explicit shape
-    knob or the LDS-tile route keep the classic kernel.  Ten steps against the reference's AVX stepper."""
-    for n, expect in ((300, True), (500, True), (2000, True), (4000, True), (10000, False), (65536, False)):
-        _, part, m = bench_universe(n)
-        plan = nb.plan_launch(n, m)
-        assert (plan["lanes"] > 1) == expect, (n, plan)
-        sim = nb.SimPipeline(n, m)
-        sim.set_data(part)
-        sim.update(10, 0.01)
-        shape = sim.launch_shape()
-        ms, launches = sim.last_step_ms()
-        got = sim.get_data()
-        sim.close()
-        assert (shape["lanes"] > 1) == expect, (n, shape)
-        if expect:
-            assert (shape["lanes"], shape["w"]) == (plan["lanes"], plan["lanes_w"]) and launches == 10 and shape["split"] == 1
-        if n <= 4000:
-            want = ob.step(part, m, 0.01, 10, kind="avx")
-            assert rel_l2_pos(got, want) <= 1e-6 and rel_displacement(got, want, part) <= DISPLACEMENT_TOL, n
-    _, part, m = bench_universe(2000)
-    for knobs in (dict(k=2), dict(w=8), dict(split=3), dict(unit=16), dict(variant=0), dict(lanes=1)):
-        sim = nb.SimPipeline(2000, m)
-        sim.configure(**knobs)
-        sim.set_data(part)
-        sim.update(1, 0.01)
-        assert sim.launch_shape()["lanes"] == 1, knobs
-        sim.close()
-    g = nb.LocalShardGroup(2000, m, 2)
-    g.set_data(part)
-    g.step(1, 0.01)
-    assert g.members[0].launch_shape()["lanes"] == 1
-    g.close()
-    # deterministic, and the same bits through the World surface
-    a = run(part, m, 3, 0.01)
-    assert a.tobytes() == run(part, m, 3, 0.01).tobytes()
-    w = nb.World(nb.make_galaxies(2000, 2, seed=11037))
-    w.update_gpu(0.01, 3)
-    assert w.particles().tobytes() == a.tobytes()
-    w.close()
-
-
-@pytest.mark.parametrize("n,frac", [(1, 1.0), (2, 0.5), (15, 1.0), (16, 0.5), (17, 1.0), (63, 0.5), (64, 1.0), (65, 0.3), (130, 1.0),
-                                    (257, 0.02), (300, 0.0), (1000, 0.01)])
-def test_lane_split_ragged_worlds(n, frac):
-    part, m = synth(n, frac, seed=3 * n + 1)
-    for lanes, w in ((4, 8), (8, 16), (2, 16)):
-        got = run(part, m, 1, 0.02, lanes=lanes, w=w, fused_chain=0)
-        check_one_step(got, part, m, 0.02)
-        two = run(part, m, 2, 0.02, lanes=lanes, w=w, fused_chain=0)
-        again = run(got, m, 1, 0.02, lanes=lanes, w=w, fused_chain=0)   # step 2 from step 1's output: the same bits
-        assert two.tobytes() == again.tobytes()
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -1004,20 +560,6 @@ def test_baseline_sizes_spot_check(n, steps, dt, variant):
     sim.close()
 
 
-def bench_universe(n):
-    """srand(11037) MakeGalaxies(n, 2) through CreateWorld's partition: the bench's universe at size n."""
-    ic = nb.make_galaxies(n, 2, seed=11037)
-    w = nb.World(ic)
-    part = w.particles()
-    w.close()
-    return ic, part, int((part[:, 6] > 0).sum())
-
-
-def rel_l2_pos(got, want):
-    d = got[:, 0:2].astype(np.float64) - want[:, 0:2].astype(np.float64)
-    return float(np.linalg.norm(d) / np.linalg.norm(want[:, 0:2].astype(np.float64)))
-
-
 def test_ten_steps_at_config2_size_against_the_avx_path():
     """BASELINE config 2 (N = 65 536), TEN steps at dt = 0.01 -- the reference semantics world.c:99-110 x 10 -- against
     the bit-exact restatement of the reference's AVX stepper (sim_cpu.c:156-194), single pipeline and through P = 8
@@ -1042,12 +584,6 @@ def test_ten_steps_at_config2_size_against_the_avx_path():
         assert rel_l2_pos(sharded, got) <= 1e-6
         assert rel_displacement(sharded, want, part) <= DISPLACEMENT_TOL, f"P=8 overlap={overlap}"
         assert np.array_equal(sharded[:, 6:8], want[:, 6:8])
-
-
-# |acc_gpu - acc_avx| <= C(N) * sum_j |contribution_j| on a 2 000-receiver sample of one step, and K steps against the AVX
-# stepper relative to what they moved.  Constants = ~3x what tools/gpu_vs_avx.py measured (profiles/r04_gpu_vs_avx.txt);
-# the deviation is the AVX path's own sequential-sum error, which grows with M (the float64 columns there show it).
-GPU_VS_AVX = {65536: (1.0e-4, 10), 262144: (5.0e-4, 10), 1 << 20: (1.0e-3, 2)}
 
 
 @pytest.mark.parametrize("n", sorted(GPU_VS_AVX))
@@ -1161,881 +697,3 @@ def test_world_level_path_at_baseline_size():
     idx = np.unique(np.random.default_rng(11).integers(0, n, 200)).astype(np.uint32)
     acc64, mag = ob.acc_f64_subset(two, m, idx)
     assert np.all(np.abs(three[idx, 4:6].astype(np.float64) - acc64) <= acc_bound(acc64, mag))
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# sharded pipeline on one GPU: local transport (all ranks in this process) and RCCL with one rank
-# ---------------------------------------------------------------------------------------------------------------
-
-@pytest.mark.parametrize("P", [2, 3, 8])
-@pytest.mark.parametrize("n", [4096, 333])
-def test_local_shard_group_single_slice_is_bitwise_equal(golden, n, P):
-    # w = 1: every receiver adds the sources in index order, pads add exact zeros -> same bits as one GPU
-    part, m = ob.partition(golden(f"ic_{n}.bin"))
-    want = run(part, m, 3, 0.01, w=1, k=1)
-    g = nb.LocalShardGroup(n, m, P, w=1, k=1)
-    g.set_data(part)
-    g.step(3, 0.01)
-    outs = [g.get_data(r) for r in range(P)]
-    g.close()
-    for o in outs:
-        assert o.tobytes() == want.tobytes()
-
-
-@pytest.mark.parametrize("overlap,split", [(0, 0), (1, 0), (0, 3)])
-@pytest.mark.parametrize("P", [2, 8])
-def test_local_shard_group_default_shape_within_tolerance(golden, P, overlap, split):
-    part, m = ob.partition(golden("ic_4096.bin"))
-    g = nb.LocalShardGroup(4096, m, P, overlap=overlap, split=split)
-    g.set_data(part)
-    g.step(1, 0.01)
-    got = g.get_data(P - 1)
-    g.step(9, 0.01)
-    ten = g.get_data(0).astype(np.float64)
-    g.close()
-    check_one_step(got, part, m, 0.01)
-    want = ob.step(part, m, 0.01, 10).astype(np.float64)
-    assert np.linalg.norm(ten[:, 0:2] - want[:, 0:2]) / np.linalg.norm(want[:, 0:2]) <= 1e-6
-    assert rel_displacement(ten, want, part) <= DISPLACEMENT_TOL
-
-
-@pytest.mark.parametrize("overlap", [0, 1])
-def test_local_shard_group_config4_shape(overlap):
-    """BASELINE config 4/5 in miniature: 8 shards of a 65536-particle universe, spot-checked against float64."""
-    n, P = 65536, 8
-    ic = nb.make_galaxies(n, 2, seed=11037)
-    w = nb.World(ic)
-    part = w.particles()
-    w.close()
-    m = int((part[:, 6] > 0).sum())
-    g = nb.LocalShardGroup(n, m, P, overlap=overlap)
-    g.set_data(part)
-    g.step(1, 0.01)
-    got = g.get_data(3)
-    g.close()
-    idx = np.unique(np.random.default_rng(8).integers(0, n, 800)).astype(np.uint32)
-    acc64, mag = ob.acc_f64_subset(part, m, idx)
-    assert np.all(np.abs(got[idx, 4:6].astype(np.float64) - acc64) <= acc_bound(acc64, mag))
-    v = part[:, 2:4] + got[:, 4:6] * np.float32(0.01)
-    assert np.array_equal(got[:, 2:4], v) and np.array_equal(got[:, 0:2], part[:, 0:2] + v * np.float32(0.01))
-    assert np.array_equal(got[:, 6:8], part[:, 6:8])
-
-
-def test_local_shard_group_full_size_config4():
-    """BASELINE config 4 at full size, all 8 shards on this one GPU: N = 2^20, two source passes per shard step."""
-    n, P = 1 << 20, 8
-    ic = nb.make_galaxies(n, 2, seed=11037)
-    w = nb.World(ic)
-    part = w.particles()
-    w.close()
-    m = int((part[:, 6] > 0).sum())
-    g = nb.LocalShardGroup(n, m, P)
-    g.set_data(part)
-    g.step(1, 0.01)
-    got = g.get_data(5)
-    g.close()
-    idx = np.unique(np.concatenate([[0, m - 1, m, n - 1], np.random.default_rng(3).integers(0, n, 400)])).astype(np.uint32)
-    acc64, mag = ob.acc_f64_subset(part, m, idx)
-    assert np.all(np.abs(got[idx, 4:6].astype(np.float64) - acc64) <= acc_bound(acc64, mag))
-    v = part[:, 2:4] + got[:, 4:6] * np.float32(0.01)
-    assert np.array_equal(got[:, 2:4], v) and np.array_equal(got[:, 0:2], part[:, 0:2] + v * np.float32(0.01))
-
-
-def test_local_shard_group_full_size_config5_overlapped():
-    """BASELINE config 5 at full size, all 8 shards on this one GPU: N = 2^22, own-slice kernel overlapped with
-    the gather, then the remote-slice kernel (several source passes each)."""
-    n, P = 1 << 22, 8
-    ic = nb.make_galaxies(n, 2, seed=11037)
-    w = nb.World(ic)
-    part = w.particles()
-    w.close()
-    m = int((part[:, 6] > 0).sum())
-    g = nb.LocalShardGroup(n, m, P, overlap=1)
-    g.set_data(part)
-    g.step(1, 0.01)
-    got = g.get_data(2)
-    g.close()
-    idx = np.unique(np.concatenate([[0, m - 1, m, n - 1], np.random.default_rng(5).integers(0, n, 200)])).astype(np.uint32)
-    acc64, mag = ob.acc_f64_subset(part, m, idx)
-    assert np.all(np.abs(got[idx, 4:6].astype(np.float64) - acc64) <= acc_bound(acc64, mag))
-    v = part[:, 2:4] + got[:, 4:6] * np.float32(0.01)
-    assert np.array_equal(got[:, 2:4], v) and np.array_equal(got[:, 0:2], part[:, 0:2] + v * np.float32(0.01))
-    assert np.array_equal(got[:, 6:8], part[:, 6:8])
-
-
-@pytest.mark.parametrize("passes", [1, 2, 5])
-def test_source_passes(golden, passes):
-    # a step cut into `passes` launches over consecutive source sub-ranges, chained through acc[]
-    part, m = ob.partition(golden("ic_4096.bin"))
-    got = run(part, m, 1, 0.01, passes=passes)
-    check_one_step(got, part, m, 0.01)
-    assert run(part, m, 4, 0.01, passes=passes, graph=1).tobytes() == run(part, m, 4, 0.01, passes=passes, graph=0).tobytes()
-    assert run(part, m, 1, 0.01, passes=passes, split=3).shape == part.shape
-
-
-def test_local_shard_group_ragged(golden):
-    part, m = synth(1000, 0.013, seed=4)      # 13 sources over 4 ranks: some ranks own no source
-    g = nb.LocalShardGroup(1000, m, 4)
-    g.set_data(part)
-    g.step(1, 0.02)
-    got = g.get_data(2)
-    g.close()
-    check_one_step(got, part, m, 0.02)
-
-
-def test_rccl_path_with_one_rank_in_a_subprocess(golden, tmp_path):
-    """NB_HIP_FORCE_SHARDED=1: dlopen librccl, ncclCommInitRank(1 rank), in-place all-gathers; plain, overlapped and
-    hipGraph-captured chains."""
-    code = r'''
-import os, sys, numpy as np
-sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, %(root)r)
-import nbody_amd as nb, oracle_binding as ob
-ic = np.fromfile(os.path.join(%(root)r, "tests/golden/ic_1024.bin"), dtype=np.float32).reshape(-1, 8)
-part, m = ob.partition(ic)
-uid = nb.comm_unique_id()
-L = nb.hip_lib()
-outs = []
-for overlap, sgraph in ((0, 0), (1, 0), (0, 1)):
-    sim = nb.SimPipeline.__new__(nb.SimPipeline)
-    import ctypes as C
-    buf = (C.c_ubyte * 128).from_buffer_copy(nb.comm_unique_id())
-    sim._h = L.CreateSimPipelineSharded(nb.WorldData(1024, m, 0.0), 0, 1, buf)
-    sim.total_len, sim.mass_len, sim.rank, sim.nranks = 1024, m, 0, 1
-    sim.configure(w=1, k=1, overlap=overlap, sharded_graph=sgraph)
-    sim.set_data(part); sim.update(3, 0.01); sim.update(3, 0.01); outs.append(sim.get_data()); sim.close()
-plain = nb.SimPipeline(1024, m); plain.configure(w=1, k=1); plain.set_data(part); plain.update(6, 0.01)
-want = plain.get_data(); plain.close()
-assert outs[0].tobytes() == want.tobytes(), "rccl 1-rank path differs"
-assert outs[1].tobytes() == want.tobytes(), "rccl 1-rank overlap path differs"
-assert outs[2].tobytes() == want.tobytes(), "rccl 1-rank captured-graph path differs"
-print("RCCL-ONE-RANK-OK")
-''' % {"root": nb.ROOT}
-    env = dict(os.environ, NB_HIP_FORCE_SHARDED="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
-
-
-def test_one_rank_rccl_reports_its_communicator_and_gather_time(golden):
-    """The evidence keys of a multi-GPU run, on the one rank a single-GPU box allows: ncclCommCount says 1, the probe
-    all-gather was timed, and per-step kernel / gather intervals come back non-zero.  In a subprocess: the knob is an
-    environment variable read at creation."""
-    code = r'''
-import os, sys, numpy as np
-sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, %(root)r)
-import nbody_amd as nb, oracle_binding as ob
-ic = np.fromfile(os.path.join(%(root)r, "tests/golden/ic_4096.bin"), dtype=np.float32).reshape(-1, 8)
-part, m = ob.partition(ic)
-sim = nb.SimPipeline(4096, m, rank=0, nranks=1, unique_id=nb.comm_unique_id())
-info = sim.comm_info()
-assert info["owns_comm"] and info["nranks"] == 1 and info["rank"] == 0 and info["rccl_version"] > 0, info
-assert info["first_gather_ms"] > 0 and "rccl" in info["rccl_lib"], info
-sim.set_data(part)
-for overlap in (0, 1):
-    sim.configure(overlap=overlap)
-    sim.update(5, 0.01)
-    steps, k_ms, c_ms = sim.step_breakdown()
-    assert steps == 5 and k_ms > 0 and c_ms > 0, (overlap, steps, k_ms, c_ms)
-    total, launches = sim.last_step_ms()
-    assert total > 0 and k_ms <= total * 1.05
-plain = nb.SimPipeline(4096, m)
-assert plain.comm_info()["owns_comm"] is False and plain.step_breakdown()[0] == 0
-plain.close(); sim.close()
-print("RCCL-EVIDENCE-OK")
-''' % {"root": nb.ROOT}
-    env = dict(os.environ, NB_HIP_FORCE_SHARDED="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "RCCL-EVIDENCE-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
-
-
-def test_sharded_world_surface_with_one_rccl_rank(golden):
-    """CreateWorldSharded (include/nbody.h extension) with the one rank this box has: the World's coherence protocol on
-    top of the RCCL pipeline -- GPU steps, collective read-back, a CPU step on the gathered array, re-upload -- gives
-    the ordinary World's state."""
-    code = r'''
-import os, sys, numpy as np
-sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, %(root)r)
-import nbody_amd as nb
-ic = np.fromfile(os.path.join(%(root)r, "tests/golden/ic_1024.bin"), dtype=np.float32).reshape(-1, 8)
-def drive(w):
-    out = []
-    w.update_gpu(0.01, 2); out.append(w.particles())
-    w.update_cpu(0.01, 1); w.update_gpu(0.01, 3); out.append(w.particles())
-    w.update_gpu(0.005, 1); w.update_gpu(0.005, 1); out.append(w.particles())
-    w.close()
-    return out
-plain = drive(nb.World(ic))
-nb.hip_lib()
-shard = drive(nb.World(ic, rank=0, nranks=1, unique_id=nb.comm_unique_id()))
-for a, b in zip(plain, shard):
-    d = a[:, 0:2].astype(np.float64) - b[:, 0:2]
-    assert np.linalg.norm(d) / np.linalg.norm(a[:, 0:2].astype(np.float64)) <= 1e-7
-    assert np.array_equal(a[:, 6:8], b[:, 6:8])
-print("SHARDED-WORLD-OK")
-''' % {"root": nb.ROOT}
-    env = dict(os.environ, NB_HIP_FORCE_SHARDED="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "SHARDED-WORLD-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
-
-
-@pytest.mark.parametrize("mode,rendezvous", [("plain", "socket"), ("sharded_graph", "socket"), ("plain", "gloo")])
-def test_bench_under_torchrun_with_one_forced_sharded_rank(mode, rendezvous):
-    """bench.py exactly as the driver launches it for N > 1 (python -m torch.distributed.run ... bench.py --gpus N),
-    with the one rank this box has and NB_HIP_FORCE_SHARDED=1.  Default rendezvous (stdlib socket hub): torch is never
-    imported, so the data path binds /opt/rocm's HIP runtime and librccl -- the stack the whole GPU suite runs on;
-    `--rendezvous gloo` is round 3's route (torch first: its bundled runtime and RCCL).  Asserts the communicator
-    evidence, non-zero gather time, the self-check against the plain single-GPU pipeline, and the extra_configs
-    entries (plain + overlapped) at a second size."""
-    import json
-    env = dict(os.environ, NB_HIP_FORCE_SHARDED="1", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4",
-               NB_HIP_SHARDED_GRAPH="1" if mode == "sharded_graph" else "0")
-    port = {("plain", "socket"): "29731", ("sharded_graph", "socket"): "29732", ("plain", "gloo"): "29733"}[(mode, rendezvous)]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-           "--master-port", port, os.path.join(nb.ROOT, "bench.py"), "--gpus", "1",
-           "--steps", "4", "--warmup", "2", "--particles", "65536", "--extra-particles", "131072", "--rendezvous", rendezvous]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=nb.ROOT)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 1 and out["value"] > 1e11
-    assert out["rccl_nranks"] == 1 and out["rccl"]["ranks_with_communicator"] == 1 and out["rccl"]["version"] > 0
-    assert out["runtime"]["torch_imported_first"] is (rendezvous == "gloo") and out["runtime"]["hip_runtime_version"] > 0
-    assert ("torch" in out["rccl"]["lib"]) == (rendezvous == "gloo"), out["rccl"]["lib"]     # which librccl the run bound
-    check = out["self_check"]
-    assert check["ranks_agree"] is True and check["static_fields_equal"] is True and check["steps"] == 6
-    assert check["vs_single_gpu_rel_l2_pos"] <= 1e-7     # one rank: same sources, same order up to the launch shape
-    if mode == "plain":
-        assert out["comm_ms_per_step"]["max"] > 0 and out["kernel_ms_per_step"]["max"] > 0
-    extra = out["extra_configs"]
-    # overlapped step; config 5 x 2; the RCCL-free direct exchange on the headline workload (with its own self-check); and last
-    # -- so that a stall there cannot cost the others -- the {kernel, ncclAllGather} x K chain captured as a hipGraph (north star)
-    assert [(e["overlap"], e["sharded_graph"]) for e in extra] == [(1, 0), (0, 0), (1, 0), (0, 0), (0, 1)]
-    assert extra[3]["transport"].startswith("direct") and extra[3]["self_check"]["ok"] is True
-    assert extra[3]["cross_device_parity"].startswith("unpinned")      # one device here: nothing crossed xGMI
-    assert all(e["value"] > 1e11 for e in extra) and "extras_aborted" not in out
-    assert extra[4]["graph_stats"]["cached"] >= 1        # RCCL inside stream capture, instantiated and replayed
-    assert all(e["comm_ms_per_step"]["max"] > 0 for e in extra if not e["sharded_graph"] and (e["overlap"] == 1 or mode == "plain"))
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# drop-in: the reference's own world.c / bench.c on top of libnbody_hip.so (oracle/_ref travels prebuilt)
-# ---------------------------------------------------------------------------------------------------------------
-
-@pytest.mark.skipif(not os.path.exists(ob.REF_WORLD_SO), reason="oracle/_ref/libnbody_ref_world.so not built")
-def test_reference_world_c_drives_our_hip_pipeline(golden):
-    nb.hip_lib()
-    ref = C.CDLL(ob.REF_WORLD_SO)
-    ref.CreateWorld.restype = C.c_void_p
-    ref.CreateWorld.argtypes = [C.c_void_p, C.c_uint32]
-    ref.GetWorldParticles.restype = C.c_void_p
-    ref.GetWorldParticles.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
-    ref.UpdateWorld_GPU.argtypes = [C.c_void_p, C.c_float, C.c_uint32]
-    ref.UpdateWorld_CPU.argtypes = [C.c_void_p, C.c_float, C.c_uint32]
-    ref.DestroyWorld.argtypes = [C.c_void_p]
-    ic = golden("ic_1024.bin")
-    w = ref.CreateWorld(ic.ctypes.data, 1024)
-    ref.UpdateWorld_GPU(w, 0.01, 2)
-    ref.UpdateWorld_CPU(w, 0.01, 1)
-    ref.UpdateWorld_GPU(w, 0.01, 1)
-    n = C.c_uint32()
-    p = ref.GetWorldParticles(w, C.byref(n))
-    got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n.value, 8)).copy()
-    ref.DestroyWorld(w)
-    ours = nb.World(ic)
-    ours.update_gpu(0.01, 2)
-    ours.update_cpu(0.01, 1)
-    ours.update_gpu(0.01, 1)
-    want = ours.particles()
-    ours.close()
-    assert got.tobytes() == want.tobytes()
-
-
-def test_nbody_bench_gpu_column():
-    """nbody-bench --gpu: the GPU column alone (reference src/bench.c:41-74 with --gpu), and -- with --verify 5 -- what that
-    column computed: 5 steps of UpdateWorld_GPU against 5 steps of UpdateWorld_CPU per row, printed and asserted."""
-    import re
-    exe = os.path.join(nb.LIB_DIR, "nbody-bench")
-    r = subprocess.run([exe, "--gpu", "--n", "4000", "--n", "20000", "--steps", "10", "--warmup", "2", "--dt", "0.01", "--verify", "5"],
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    rows = [l.split() for l in r.stdout.strip().splitlines()]
-    assert rows[0][:2] == ["N", "GPU"] and [x[0] for x in rows[1:]] == ["4000", "20000"]
-    assert all(float(x[2]) > 1e9 for x in rows[1:])
-    # us/step x interactions/s = N x M of the row: the two printed figures describe the same run
-    for x, n in zip(rows[1:], (4000, 20000)):
-        pairs = float(x[1]) * 1e-6 * float(x[2])
-        assert 0.3 * n * n <= pairs <= 0.7 * n * n, (x, pairs)      # M ~ N / 2 with galaxy.h ICs
-    devs = [float(v) for v in re.findall(r"GPU vs CPU rel_displacement ([0-9.e+-]+)", r.stderr)]
-    assert len(devs) == 2 and all(d <= 1e-5 for d in devs), r.stderr      # stated tolerance 1e-4; observed ~1e-6
-    assert r.stderr.count("mass/radius equal yes") == 2
-
-
-def test_nbody_bench_verify_column_compares_gpu_with_the_cpu_path():
-    """nbody-bench --verify K: K steps of UpdateWorld_GPU against K steps of UpdateWorld_CPU (bit-exact with the reference
-    AVX build, tests/test_world_cpu.py) per row, relative to what the steps moved; the harness itself fails above 1e-4."""
-    import re
-    exe = os.path.join(nb.LIB_DIR, "nbody-bench")
-    r = subprocess.run([exe, "--n", "1200", "--n", "10000", "--steps", "5", "--warmup", "1", "--dt", "0.01", "--verify", "10"],
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    devs = [float(x) for x in re.findall(r"GPU vs CPU rel_displacement ([0-9.e+-]+)", r.stderr)]
-    assert len(devs) == 2 and all(d <= 1e-5 for d in devs), r.stderr      # observed ~1e-6: summation order only
-    assert r.stderr.count("mass/radius equal yes") == 2
-
-
-def test_rccl_watchdog_arms_per_wait_and_fires_on_a_wait_that_overruns(golden):
-    """The blocking waits of an RCCL pipeline run under ONE long-lived watcher thread that is armed with a deadline and
-    disarmed again (rccl_bind.hip): 300 short blocking calls arm / disarm it without tripping, and a chain that outlasts
-    NB_HIP_COMM_TIMEOUT_S ends the process with the diagnostic and exit code 3 -- no retry, no re-exec."""
-    code = ("import os, sys, numpy as np, nbody_amd as nb\n"
-            "ic = nb.make_galaxies(65536, 2, own_rng=True, seed=5)\n"
-            "w = nb.World(ic); part = w.particles(); w.close(); m = int((part[:, 6] > 0).sum())\n"
-            "sim = nb.SimPipeline(65536, m, rank=0, nranks=1, unique_id=nb.comm_unique_id())\n"
-            "assert sim.comm_info()['owns_comm']\n"
-            "sim.set_data(part)\n"
-            "os.environ['NB_HIP_COMM_TIMEOUT_S'] = '2'   # read at every wait; the communicator's creation had the default\n"
-            "for _ in range(300): sim.update(1, 0.01)\n"
-            "print('SHORT CALLS OK', flush=True)\n"
-            "sim.update(int(sys.argv[1]), 0.01)\n"
-            "print('LONG CALL RETURNED', flush=True)\n")
-    env = dict(os.environ, NB_HIP_FORCE_SHARDED="1")
-    env.pop("NB_HIP_COMM_TIMEOUT_S", None)
-    ok = subprocess.run([sys.executable, "-c", code, "500"], cwd=nb.ROOT, env=env, capture_output=True, text=True, timeout=300)
-    assert ok.returncode == 0 and "LONG CALL RETURNED" in ok.stdout, (ok.stdout, ok.stderr[-2000:])   # ~0.25 s: inside the bound
-    late = subprocess.run([sys.executable, "-c", code, "12000"], cwd=nb.ROOT, env=env, capture_output=True, text=True, timeout=300)
-    assert late.returncode == 3, (late.returncode, late.stdout, late.stderr[-2000:])                    # ~5 s of steps against 2 s
-    assert "SHORT CALLS OK" in late.stdout and "LONG CALL RETURNED" not in late.stdout
-    assert "[watchdog] rank 0 of 1" in late.stderr and "did not complete within 2 s" in late.stderr
-
-
-def test_explicit_lanes_or_route_keeps_the_per_step_kernel_on_tiny_worlds():
-    """ADVICE r3: "fused_chain" auto applies only while the launch shape is on auto -- an explicit lanes / variant asks for
-    the per-step kernel also on a world small enough for the one-workgroup chain."""
-    part, m = synth(250, 0.5, seed=11)
-    want = run(part, m, 10, 0.01, fused_chain=0, lanes=4)
-    for knobs, fused in ((dict(), 10), (dict(lanes=4), 0), (dict(variant=0), 0), (dict(lanes=1), 0)):
-        sim = nb.SimPipeline(250, m)
-        sim.configure(**knobs)
-        sim.set_data(part)
-        sim.update(10, 0.01)
-        assert sim.fused_steps() == fused, (knobs, sim.fused_steps())
-        if knobs == dict(lanes=4):
-            assert sim.launch_shape()["lanes"] == 4 and sim.get_data().tobytes() == want.tobytes()
-        sim.close()
-
-
-def test_gpu_work_leaves_the_callers_rand_stream_alone():
-    """The reference harness seeds libc's rand() once and draws every universe of its table from it between GPU calls
-    (src/bench.c:42,53); the HIP runtime's first set-up draws from the same process-global state.  The library swaps a
-    private state in around it (RandGuard): in a fresh process, the values after srand(1) are the same with and
-    without a World's whole GPU life in between."""
-    code = ("import ctypes as C, numpy as np, nbody_amd as nb\n"
-            "libc = C.CDLL(None); libc.srand(1); plain = [libc.rand() for _ in range(5)]\n"
-            "ic = nb.make_galaxies(2000, 2, own_rng=True, seed=3)\n"
-            "libc.srand(1)\n"
-            "w = nb.World(ic); w.update_gpu(0.01, 3); w.particles(); w.update_gpu(0.01, 40); w.close()\n"
-            "got = [libc.rand() for _ in range(5)]\n"
-            "print('SAME' if got == plain else 'DISTURBED', plain, got)\n")
-    r = subprocess.run([sys.executable, "-c", code], cwd=nb.ROOT, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and r.stdout.startswith("SAME"), (r.stdout, r.stderr[-2000:])
-
-
-def _bench_ranks(args, env=None, timeout=600):
-    exe = os.path.join(nb.LIB_DIR, "nbody-bench")
-    e = dict(os.environ, OMP_NUM_THREADS="2")
-    e.update(env or {})
-    return subprocess.run([exe] + args, env=e, capture_output=True, text=True, timeout=timeout)
-
-
-@pytest.mark.parametrize("transport", ["shm", "ipc"])
-@pytest.mark.parametrize("P,n", [(2, 4000), (3, 1200), (3, 20000)])
-def test_nbody_bench_c_ranks_on_one_gpu_bitwise(P, n, transport):
-    """nbody-bench --gpus P --transport shm | ipc: P REAL processes forked by the C harness before anything touched HIP,
-    each with its own HIP context on this one GPU, one World stepped through CreateWorldShardedWith over the shared page
-    (shm: data staged through the host) or CreateWorldShardedDirect (ipc: every rank maps its peers' source arrays with
-    hipIpcOpenMemHandle and pushes its slice into them device to device; the page carries handles and one barrier per
-    step) -- no Python, no torch, /opt/rocm's HIP runtime.  With one wave per workgroup (--one-wave) the
-    summation order does not depend on the launch geometry: the in-stream (plain) step must equal the single-GPU World
-    bit for bit."""
-    import re
-    r = _bench_ranks(["--gpus", str(P), "--transport", transport, "--n", str(n), "--steps", "6", "--warmup", "2", "--dt", "0.01",
-                      "--modes", "plain", "--verify", "4", "--one-wave"])
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    v = re.findall(r"verify N=(\d+) mode=(\w+) steps=4: ranks agree (\w+); vs single GPU: rel_l2_pos ([0-9.e+-]+) max_abs_pos ([0-9.e+-]+) bitwise (\w+)", r.stderr)
-    assert v == [(str(n), "plain", "yes", v[0][3], v[0][4], "yes")] and float(v[0][3]) == 0.0, r.stderr
-    rows = [l.split() for l in r.stdout.strip().splitlines()]
-    assert rows[0][:4] == ["N", "ranks", "mode", "GPU"] and rows[1][:3] == [str(n), str(P), "plain"]
-    assert float(rows[1][3]) > 0 and float(rows[1][-2]) > 0 and float(rows[1][-1]) > 0     # us/step, kernel ms, gather ms
-    assert f"{P} ranks, transport {transport}; ranks_with_communicator=0" in r.stderr
-    assert ("direct device-to-device pushes" in r.stderr) == (transport == "ipc")
-
-
-@pytest.mark.parametrize("transport", ["shm", "ipc"])
-def test_nbody_bench_c_ranks_default_shapes_and_overlap(transport):
-    """The same with the library's own launch shapes, both step modes, two sizes in one run (the second World gets a
-    fresh exchange): every rank holds the same bytes and they stay within 1e-5 relative L2 of the single-GPU positions
-    (the harness' own bound; observed ~1e-8)."""
-    import re
-    r = _bench_ranks(["--gpus", "2", "--transport", transport, "--n", "4096", "--n", "65536", "--steps", "5", "--warmup", "1", "--dt", "0.01"])
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    v = re.findall(r"verify N=(\d+) mode=(\w+) steps=3: ranks agree (\w+); vs single GPU: rel_l2_pos ([0-9.e+-]+)", r.stderr)
-    assert [(a, b, c) for a, b, c, _ in v] == [("4096", "plain", "yes"), ("4096", "overlap", "yes"), ("65536", "plain", "yes"),
-                                               ("65536", "overlap", "yes")], r.stderr
-    assert all(float(x[3]) <= 1e-6 for x in v)
-    rows = [l.split() for l in r.stdout.strip().splitlines()][1:]
-    assert [(x[0], x[2]) for x in rows] == [("4096", "plain"), ("4096", "overlap"), ("65536", "plain"), ("65536", "overlap")]
-    assert all(float(x[5]) > 1e9 for x in rows)
-    # --speedup: rank 0 times the same call on a single-GPU World; with every rank on ONE GPU the "speedup" is below 1
-    r = _bench_ranks(["--gpus", "2", "--transport", transport, "--n", "20000", "--steps", "5", "--warmup", "1", "--dt", "0.01",
-                      "--modes", "plain", "--verify", "0", "--speedup"])
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    head, row = [l.split() for l in r.stdout.strip().splitlines()]
-    assert head[-2:] == ["us", "speedup"] and 0.05 < float(row[-1]) < 1.5 and float(row[-2]) > 10
-    # ... and a multi-rank row is never printed unchecked: --verify 0 is overridden (one step, ranks agree, = one GPU)
-    assert "--verify 0 is not accepted with --gpus 2" in r.stderr and "verify N=20000 mode=plain steps=1: ranks agree yes" in r.stderr
-
-
-def test_nbody_bench_c_one_forced_rccl_rank():
-    """nbody-bench --gpus 1 --force-sharded: the RCCL path (ncclCommInitRank, in-place ncclAllGather per step, the chain
-    captured as a hipGraph, the overlapped step) with ONE rank, forked by the C harness -- the HIP runtime and librccl
-    this binds are /opt/rocm's (no torch in the process), which is what a real --gpus 8 run binds too."""
-    import re
-    r = _bench_ranks(["--gpus", "1", "--force-sharded", "--n", "20000", "--steps", "8", "--warmup", "2", "--dt", "0.01"])
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    assert "1 ranks, transport rccl; ranks_with_communicator=1 ncclCommCount=1..1" in r.stderr
-    lib = re.search(r"lib=(\S+)", r.stderr).group(1)
-    assert "librccl" in lib and "torch" not in lib, lib
-    v = re.findall(r"mode=(\w+) steps=3: ranks agree yes; vs single GPU: rel_l2_pos ([0-9.e+-]+)", r.stderr)
-    assert [m for m, _ in v] == ["plain", "overlap", "graph"] and all(float(x) <= 1e-6 for _, x in v), r.stderr
-    rows = [l.split() for l in r.stdout.strip().splitlines() if l.split() and l.split()[0] == "20000"]
-    assert [x[2] for x in rows] == ["plain", "overlap", "graph"] and all(float(x[5]) > 1e9 for x in rows)
-
-
-def test_nbody_bench_c_ranks_refuses_rccl_without_enough_devices():
-    if nb.device_count() >= 2:
-        pytest.skip("more than one GPU here")
-    r = _bench_ranks(["--gpus", "2", "--transport", "rccl", "--n", "1200", "--steps", "2"], timeout=120)
-    assert r.returncode != 0 and "needs 2 (one per rank)" in r.stderr and "transport_fallback" not in r.stderr
-
-
-def test_nbody_bench_c_falls_back_to_the_direct_exchange_in_fresh_ranks():
-    """nbody-bench --gpus 2 with the default --transport auto on a one-GPU box: the RCCL attempt's ranks end with an error
-    (two ranks, one device), the parent -- which never touches HIP -- forks a FRESH set of ranks over the direct exchange,
-    says so on both streams, and the table of the second attempt is verified against a single-GPU World like any other
-    (VERDICT r4 item 1b, the C harness' half; reference shape: one plain command, src/bench.c:41-74)."""
-    import re
-    if nb.device_count() >= 2:
-        pytest.skip("more than one GPU here: the RCCL attempt would succeed")
-    r = _bench_ranks(["--gpus", "2", "--n", "20000", "--steps", "5", "--warmup", "1", "--dt", "0.01"], timeout=300)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    assert "transport_fallback rccl -> ipc" in r.stderr and "2 ranks, transport ipc" in r.stderr
-    lines = r.stdout.strip().splitlines()
-    mark = next(i for i, l in enumerate(lines) if l.startswith("# transport_fallback rccl -> ipc"))
-    rows = [l.split() for l in lines[mark + 2:]]       # header, then one row per mode (plain, overlap: no captured graph over ipc)
-    assert [(x[0], x[2]) for x in rows] == [("20000", "plain"), ("20000", "overlap")] and all(float(x[5]) > 1e9 for x in rows)
-    v = re.findall(r"verify N=20000 mode=(\w+) steps=3: ranks agree (\w+); vs single GPU: rel_l2_pos ([0-9.e+-]+)", r.stderr)
-    assert [(a, b) for a, b, _ in v] == [("plain", "yes"), ("overlap", "yes")] and all(float(x[2]) <= 1e-6 for x in v)
-    # preflight (VERDICT r5 item 1c): every rank of the ipc attempt wrote its device, peer row and one IPC open of the next rank
-    pre = re.findall(r"# preflight rank (\d) of 2 transport=ipc device=0/1 pci=(\S+) can_access_peer=\[1\] ipc_export=0 ipc_open\(rank (\d)\)=0 ", r.stderr)
-    assert sorted((a, c) for a, _, c in pre) == [("0", "1"), ("1", "0")] and len({b for _, b, _ in pre}) == 1, r.stderr[-3000:]
-
-
-def test_nbody_bench_c_walks_to_shm_when_the_driver_refuses_ipc():
-    """The C harness' whole chain, nothing rehearsed: with the IPC mode this pool's driver does not serve
-    (HSA_ENABLE_IPC_MODE_LEGACY=1: hipIpcGetMemHandle -> invalid argument) `nbody-bench --gpus 2` goes rccl (status 2: one device
-    for two ranks) -> ipc (status 134: abort() at the first IPC export, which the preflight line had already reported) -> shm,
-    whose table is verified against a single-GPU World like any other (profiles/r06_legacy_ipc_cbench.txt is this run, kept)."""
-    import re
-    if nb.device_count() >= 2:
-        pytest.skip("more than one GPU here: the RCCL attempt would succeed")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="1", OMP_NUM_THREADS="4")
-    r = subprocess.run([os.path.join(nb.LIB_DIR, "nbody-bench"), "--gpus", "2", "--n", "65536", "--steps", "5", "--warmup", "1", "--dt", "0.01"],
-                       env=env, capture_output=True, text=True, timeout=600, cwd=nb.ROOT)
-    marks = [l for l in r.stdout.splitlines() if l.startswith("# transport_fallback")]
-    if len(marks) == 1 and r.returncode == 0:
-        pytest.skip("this box's driver serves the legacy IPC mode: the direct exchange came up")
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    assert [m.split("(")[0].strip() for m in marks] == ["# transport_fallback rccl -> ipc", "# transport_fallback ipc -> shm"]
-    assert "bring_up_failed, status 2" in marks[0] and "bring_up_failed, status 134" in marks[1]
-    assert len(re.findall(r"# preflight rank \d of 2 transport=ipc .* ipc_export=[1-9]\d* \(", r.stderr)) == 2     # said why, before the abort
-    assert len(re.findall(r"# preflight rank \d of 2 transport=shm .* ipc=not probed", r.stderr)) == 2
-    rows = [l.split() for l in r.stdout.splitlines() if l.split() and l.split()[0] == "65536"]
-    assert [(x[1], x[2]) for x in rows] == [("2", "plain"), ("2", "overlap")] and all(float(x[5]) > 1e11 for x in rows)
-    v = re.findall(r"verify N=65536 mode=(\w+) steps=3: ranks agree (\w+); vs single GPU: rel_l2_pos ([0-9.e+-]+)", r.stderr)
-    assert [(a, b) for a, b, _ in v] == [("plain", "yes"), ("overlap", "yes")] and all(float(x[2]) <= 1e-6 for x in v)
-    assert "verification_failed" not in r.stdout + r.stderr
-
-
-@pytest.mark.skipif(not os.path.exists(os.path.join(ob.ORACLE_DIR, "_ref", "nbody-bench-ref")),
-                    reason="oracle/_ref/nbody-bench-ref not built")
-def test_reference_bench_c_runs_unchanged_on_our_library():
-    exe = os.path.join(ob.ORACLE_DIR, "_ref", "nbody-bench-ref")
-    r = subprocess.run([exe, "--gpu"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    rows = [l.split() for l in r.stdout.strip().splitlines()]
-    assert rows[0] == ["N", "GPU"]
-    assert [int(x[0]) for x in rows[1:]] == [250, 500, 800, 1200, 2000, 4000, 10000, 20000, 50000, 100000]
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# several REAL processes through pipeline.hip's sharded host code on this one GPU (caller-supplied host transport)
-# ---------------------------------------------------------------------------------------------------------------
-
-_MULTI_PROC_WORKER = r'''
-import os, sys, numpy as np, torch, torch.distributed as dist
-root = sys.argv[1]; out_path = sys.argv[2]; n = int(sys.argv[3]); overlap = int(sys.argv[4])
-sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, root)
-import nbody_amd as nb, oracle_binding as ob
-dist.init_process_group(backend="gloo")
-rank, world = dist.get_rank(), dist.get_world_size()
-ic = np.fromfile(os.path.join(root, "tests", "golden", f"ic_{n}.bin"), dtype=np.float32).reshape(-1, 8)
-part, m = ob.partition(ic)
-calls = []
-def gather(rows, r, nr):
-    calls.append(rows.shape)
-    mine = torch.from_numpy(rows[r].copy())
-    parts = [torch.empty_like(mine) for _ in range(nr)]
-    dist.all_gather(parts, mine)
-    for q in range(nr):
-        if q != r: rows[q] = parts[q].numpy()
-res = {}
-for tag, knobs in (("w1", dict(w=1, k=1)), ("auto", dict())):
-    sim = nb.SimPipeline(n, m, rank=rank, nranks=world, allgather=gather)
-    sim.configure(overlap=overlap, **knobs)
-    sim.set_data(part)
-    sim.update(2, 0.01); sim.update(1, 0.01)
-    steps, k_ms, c_ms = sim.step_breakdown()
-    assert steps == 1 and k_ms > 0 and c_ms > 0
-    info = sim.comm_info()
-    assert not info["owns_comm"] and info["nranks"] == world and info["rank"] == rank and "host" in info["rccl_lib"]
-    res[tag] = sim.get_data()          # collective: every rank gets the full array
-    sim.close()
-plan = nb.shard_plan(n, m, rank, world)
-assert len(calls) == 2 * (3 + 1) and calls[0] == (world, plan["mass_chunk"] * 8)
-# every rank must hold the same bytes
-for tag in res:
-    mine = torch.from_numpy(res[tag].view(np.uint8).reshape(-1).copy())
-    ref = mine.clone(); dist.broadcast(ref, src=0)
-    assert bool((mine == ref).all()), f"rank {rank} differs from rank 0 ({tag})"
-if rank == world - 1:                  # written by the LAST rank: a rank > 0 produced the checked bytes
-    np.save(out_path, np.stack([res["w1"], res["auto"]]))
-dist.barrier(); dist.destroy_process_group()
-'''
-
-
-# at most 3 ranks: the GPU boxes allow 6 processes on the card, and the pytest process and the torchrun launcher count too
-@pytest.mark.parametrize("world,n,overlap", [(2, 1024, 0), (3, 333, 1), (2, 4096, 1), (3, 4096, 0)])
-def test_sharded_pipeline_with_real_processes_on_one_gpu(golden, tmp_path, world, n, overlap):
-    """pipeline.hip's sharded host code with `world` REAL processes (ranks > 0 in their own address space, collective
-    Get included), all on this one GPU: the exchange goes through the caller-supplied host transport
-    (CreateSimPipelineShardedWith) over gloo, because RCCL refuses two ranks on one device.  Everything but the
-    ncclAllGather call itself is the RCCL path's code.  W = 1, gather in-stream: bit-equal to the single pipeline; auto shape: within
-    the one-step tolerance chain (three steps, positions <= 1e-6 relative L2 of the single pipeline)."""
-    worker = tmp_path / "worker.py"
-    worker.write_text(_MULTI_PROC_WORKER)
-    out = tmp_path / "out.npy"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29800 + world), str(worker), nb.ROOT, str(out), str(n), str(overlap)]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    got = np.load(out)
-    part, m = ob.partition(golden(f"ic_{n}.bin"))
-    single_w1 = run(part, m, 3, 0.01, w=1, k=1)
-    if overlap == 0:
-        assert got[0].tobytes() == single_w1.tobytes()
-    else:
-        # the overlapped step adds the rank's own slice first and the remote slices after it: another summation order
-        assert rel_l2_pos(got[0], single_w1) <= 1e-6 and np.array_equal(got[0][:, 6:8], single_w1[:, 6:8])
-    want = run(part, m, 3, 0.01)
-    assert rel_l2_pos(got[1], want) <= 1e-6
-    assert np.array_equal(got[1][:, 6:8], want[:, 6:8])
-
-
-@pytest.mark.parametrize("transport", ["host", "direct"])
-def test_bench_with_two_real_ranks_on_one_gpu(transport):
-    """bench.py as the driver launches it for N = 2 -- two processes, barriers, reductions over the ranks, self-check
-    against the single-GPU pipeline, extra_configs -- with both ranks on this one GPU over the host transport, and over
-    the direct one (slices pushed device-to-device into IPC-mapped peers, one barrier per step over the socket hub)."""
-    import json
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29741" if transport == "host" else "29742", os.path.join(nb.ROOT, "bench.py"), "--gpus", "2",
-           "--transport", transport, "--steps", "4", "--warmup", "1", "--particles", "65536", "--extra-particles", "131072"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=nb.ROOT)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    lines = r.stdout.splitlines()
-    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]      # stdout carries the JSON line only
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["value"] > 1e10 and out["rccl_nranks"] is None and out["transport"].startswith(transport)
-    assert out["rccl"]["user_ranks"] == {"min": 0, "max": 1, "sum": 1} and out["rccl"]["ranks_with_communicator"] == 0
-    check = out["self_check"]
-    assert check["ranks_agree"] is True and check["static_fields_equal"] is True and check["steps"] == 5
-    assert check["vs_single_gpu_rel_l2_pos"] <= 1e-6
-    assert out["kernel_ms_per_step"]["min"] > 0 and out["comm_ms_per_step"]["max"] > 0
-    extra = out["extra_configs"]
-    assert [(e["overlap"], e["sharded_graph"]) for e in extra] == [(1, 0), (0, 0), (1, 0), (0, 1)]
-    assert "skipped" in extra[3]              # a host callback cannot be captured into a hipGraph: RCCL transport only
-    timed = [e for e in extra if "skipped" not in e]
-    assert all(e["value"] > 1e10 and e["kernel_ms_per_step"]["max"] > 0 for e in timed)
-    assert "extras_aborted" not in out
-    # preflight (VERDICT r5 item 1c): every rank's bring-up record, written before the headline -- PCI address, the
-    # hipDeviceCanAccessPeer row, and (direct only: the host transport must not depend on IPC) one IPC open / close of the
-    # next rank's exported word
-    flights = out["preflight"]
-    assert [f["rank"] for f in flights] == [0, 1] and all(f["transport"] == transport for f in flights)
-    assert len({f["pci"] for f in flights}) == 1 and all(f["visible_devices"] >= 1 and f["can_access_peer"][0] == 1 for f in flights)
-    if transport == "direct":
-        assert all(f["ipc_export_rc"] == 0 and f["ipc_open_rc"] == 0 and f["ipc_open_peer"] == 1 - f["rank"] and f["ipc_open_ms"] > 0 for f in flights)
-    else:
-        assert all("ipc_open_rc" not in f for f in flights)
-    trail = out["launch"]["attempts"][0]["preflight"]            # what the supervisors read off the workers' stderr, stage by stage
-    assert {e["stage"] for e in trail} == ({"device", "ipc"} if transport == "direct" else {"device"})
-    assert 0 < out["roofline"]["roofline_frac_from_wall"] < 1 and out["roofline"]["traffic_measured_in_this_run"] is False
-
-
-def test_bench_line_survives_a_stuck_leg():
-    """The first real multi-GPU run must not lose its headline to a stalled optional leg: the JSON dict is complete
-    after the headline leg + self-check, every later leg runs under a host-side deadline, and on expiry rank 0 writes
-    the line with what is in hand plus "extras_aborted" and every rank leaves with a fresh non-zero exit.  Rehearsed
-    with two real ranks on this one GPU: during the 'overlap' leg the host transport's all-gather never returns."""
-    import json
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", NB_BENCH_REHEARSE='{"stall_leg": "overlap"}')
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29743", os.path.join(nb.ROOT, "bench.py"), "--gpus", "2", "--transport", "host",
-           "--steps", "4", "--warmup", "1", "--particles", "65536", "--extra-particles", "131072", "--leg-deadline-s", "10"]
-    t0 = time.time()
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=nb.ROOT)
-    assert r.returncode != 0, "a run whose leg stalled must not report success"
-    assert time.time() - t0 < 300, "the leg's deadline, not the run's budget, must end the run"
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
-    out = json.loads(lines[0])
-    assert out["extras_aborted"] == "overlap"
-    assert out["n_gpus"] == 2 and out["value"] > 1e10 and out["ms_per_step"] > 0      # the headline survived
-    assert out["self_check"]["ranks_agree"] is True and out["self_check"]["vs_single_gpu_rel_l2_pos"] <= 1e-6
-    assert out["extra_configs"] == []                                                   # no leg had finished yet
-    assert "passed its deadline" in r.stderr
-
-
-def test_bench_line_survives_a_leg_that_aborts():
-    """... and not to an optional leg that dies by the library's own error convention (print + abort(), reference
-    src/lib/util.h:17-29) either: rank 0's C-level handler writes the line prepared when the leg was armed."""
-    import json
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", NB_BENCH_REHEARSE='{"crash_leg": "config5"}')
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29745", os.path.join(nb.ROOT, "bench.py"), "--gpus", "2", "--transport", "host",
-           "--steps", "4", "--warmup", "1", "--particles", "65536", "--extra-particles", "131072"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=nb.ROOT)
-    assert r.returncode != 0
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
-    out = json.loads(lines[0])
-    assert out["extras_aborted"] == "config5 (fatal signal)" and out["value"] > 1e10
-    assert out["self_check"]["ranks_agree"] is True
-    # the leg that had finished before the crash is on the line: the overlapped step
-    assert [(e["overlap"], e["sharded_graph"]) for e in out["extra_configs"]] == [(1, 0)]
-    assert "fatal signal 6" in r.stderr
-
-
-def test_bench_auto_lands_on_the_host_transport_when_rccl_and_direct_are_refused():
-    """--transport auto with two real ranks on this ONE GPU: RCCL refuses the duplicate device for real (both ranks abort in
-    ncclCommInitRank), the direct attempt is made to fail right after its rendezvous (tests/bench_rehearsal.py), and the run
-    lands on the transport nothing can refuse -- host-staged slices over the rank link -- with two transport_fallback
-    entries, a verified headline and exit code 0 (VERDICT r5 item 1b).  Each failed attempt leaves its preflight trail."""
-    import json
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
-    env.update(OMP_NUM_THREADS="4", NB_BENCH_REHEARSE='{"fail_transports": ["direct"]}')
-    r = subprocess.run([sys.executable, os.path.join(nb.ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-                        "--particles", "65536", "--extra-particles", "131072", "--no-extras"],
-                       env=env, capture_output=True, text=True, timeout=900, cwd=nb.ROOT)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
-    assert [a["transport"] for a in out["launch"]["attempts"]] == ["rccl", "direct", "host"]
-    fb = out["transport_fallback"]
-    assert [(f["from"], f["to"], f["kind"]) for f in fb] == [("rccl", "direct", "bring_up_failed"), ("direct", "host", "bring_up_failed")]
-    assert out["transport"].startswith("host") and out["n_gpus"] == 2 and out["value"] > 1e10
-    check = out["self_check"]
-    assert check["ranks_agree"] is True and check["ok"] is True and check["vs_single_gpu_rel_l2_pos"] <= 1e-6
-    # the RCCL attempt got as far as its IPC probe and announced ncclCommInitRank before it died there
-    trail = out["launch"]["attempts"][0]["preflight"]
-    assert any(e.get("stage") == "rccl" and "entering" in e for e in trail) and any(e.get("stage") == "ipc" and e.get("ipc_open_rc") == 0 for e in trail)
-    assert out["launch"]["seconds"] < out["launch"]["budget_s"]
-
-
-def test_bench_auto_survives_a_container_that_refuses_ipc_for_real():
-    """The same chain with nothing rehearsed: HSA_ENABLE_IPC_MODE_LEGACY=1 selects the IPC mode this pool's host driver does
-    not support, so hipIpcGetMemHandle fails with `invalid argument` -- a container refusing IPC.  Two ranks on this one
-    GPU: RCCL refuses the duplicate device, the direct exchange aborts at its first IPC export, the host transport needs
-    neither and delivers a verified headline.  The preflight of the failed attempts says WHY before anything aborted:
-    ipc_export_rc != 0 with the runtime's own error string (profiles/r06_legacy_ipc_2ranks.json is this run, kept)."""
-    import json
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "NB_BENCH_REHEARSE")}
-    env.update(OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="1")
-    r = subprocess.run([sys.executable, os.path.join(nb.ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-                        "--particles", "65536", "--extra-particles", "131072", "--no-extras"],
-                       env=env, capture_output=True, text=True, timeout=900, cwd=nb.ROOT)
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
-    out = json.loads(lines[0])
-    attempts = out["launch"]["attempts"]
-    if len(attempts) == 2 and attempts[1]["child_rcs"] == [0, 0]:
-        pytest.skip("this box's driver serves the legacy IPC mode: the direct exchange came up")
-    assert r.returncode == 0, r.stderr[-3000:]
-    assert [(a["transport"], a.get("kind")) for a in attempts] == [("rccl", "bring_up_failed"), ("direct", "bring_up_failed"), ("host", None)]
-    for a in attempts[:2]:
-        ipc = [e for e in a["preflight"] if e.get("stage") == "ipc" and "ipc_export_rc" in e]
-        assert len(ipc) == 2 and all(e["ipc_export_rc"] != 0 and e["ipc_export_error"] and e["ipc_open_rc"] is None for e in ipc), a["preflight"]
-        assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "1" for e in a["preflight"] if e.get("stage") == "device")
-    assert "hipIpcGetMemHandle" in attempts[1]["stderr_tail"]          # the direct attempt died exactly where the preflight said it would
-    assert all("ipc_export_rc" not in e for e in attempts[2]["preflight"])      # the host transport never asked
-    assert out["transport"].startswith("host") and out["self_check"]["ok"] is True and out["value"] > 1e10
-    assert [(f["from"], f["to"]) for f in out["transport_fallback"]] == [("rccl", "direct"), ("direct", "host")]
-
-
-def test_host_transport_callback_that_raises_ends_the_process(golden, tmp_path):
-    """A Python exception inside the caller-supplied all-gather must not escape into ctypes (it would be swallowed
-    and the pipeline would step on stale peer slots): the thunk prints the traceback and leaves with exit code 5."""
-    worker = tmp_path / "raises.py"
-    worker.write_text(r'''
-import os, sys, numpy as np
-root = sys.argv[1]
-sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, root)
-import nbody_amd as nb, oracle_binding as ob
-part, m = ob.partition(np.fromfile(os.path.join(root, "tests", "golden", "ic_333.bin"), dtype=np.float32).reshape(-1, 8))
-def bad(rows, r, n):
-    raise RuntimeError("transport fell over")
-sim = nb.SimPipeline(333, m, rank=0, nranks=1, allgather=bad)
-sim.set_data(part)
-sim.update(1, 0.01)
-print("NOT REACHED")
-''')
-    r = subprocess.run([sys.executable, str(worker), nb.ROOT], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 5, (r.returncode, r.stderr[-2000:])
-    assert "transport fell over" in r.stderr and "all-gather raised" in r.stderr and "NOT REACHED" not in r.stdout
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# measurement aids: the clock probe and the clock sampler (include/nbody_hip.h; bench.py roofline.held_clock_ghz)
-# ---------------------------------------------------------------------------------------------------------------
-
-def test_clock_sampler_runs_beside_the_step_kernels_without_touching_their_results():
-    """nb_hip_clock_sampler_*: eight one-wave workgroups stamp the shader clock while a step chain runs on the pipeline's own
-    stream.  The chain's results are bit-identical with and without the sampler, the sampler covers the chain's span, sits
-    on several XCDs, and leaves by itself when its bound passes even if nobody stops it."""
-    n = 65536
-    _, part, m = bench_universe(n)
-    want = run(part, m, 20, 0.01)
-    sim = nb.SimPipeline(n, m)
-    sim.set_data(part)
-    assert nb.clock_sampler_begin(0.2, 4000.0) == 8
-    sim.update(20, 0.01)
-    got = sim.get_data()
-    s = nb.clock_sampler_end()
-    sim.close()
-    assert got.tobytes() == want.tobytes()
-    assert s["intervals"] >= 8 and 1.0 <= s["clock_ghz_min"] <= s["clock_ghz"] <= s["clock_ghz_max"] <= 2.45, s
-    assert s["span_ms"] >= 5.0 and sum(1 for v in s["per_xcd_ghz"] if v > 0) >= 2, s
-    assert all(1.0 <= v <= 2.45 for v in s["profile_ghz"]), s
-    # bounded: never stopped from the host, the waves leave after max_ms by themselves (end() then only collects; how long
-    # that takes is asked in tests/test_gpu_zz_perf.py)
-    nb.clock_sampler_begin(0.2, 100.0)
-    time.sleep(0.5)
-    late = nb.clock_sampler_end()
-    assert late["intervals"] >= 8 and late["span_ms"] >= 50.0, late
-
-
-@pytest.mark.skipif(not nb.hip_lib().nb_hip_tuning_build(), reason="the persistent-launch experiment kernels are built with make TUNING=1 only")
-def test_persistent_launch_equals_the_classic_launch():
-    """The persistent-launch experiment kernel (tuning hook "persist", VERDICT r4 item 7; closed: slower at every size,
-    profiles/r05_persist_probe.txt): a launch of 1/P as many workgroups whose waves walk P (tile, part) work items each runs,
-    per item, the code a classic workgroup runs -- same bits as the classic launch, with the finish kernel and with the fused
-    finish, as plain launches and inside a hipGraph; and the classic launch of that state is what the oracle checks."""
-    _, part, m = bench_universe(10000)
-    base = run(part, m, 12, 0.01, graph=0)
-    sim = nb.SimPipeline(10000, m)
-    sim.set_data(part)
-    sim.update(1, 0.01)
-    shape = sim.launch_shape()
-    one = sim.get_data()
-    sim.close()
-    check_one_step(one, part, m, 0.01)
-    fixed = {k: shape[k] for k in ("k", "w", "split", "unit")}
-    assert run(part, m, 1, 0.01, persist=2, **fixed).tobytes() == one.tobytes()
-    assert shape["split"] > 1 and shape["lanes"] == 1
-    for persist in (2, 3, 7):
-        for fused in (0, 1):
-            for graph in (0, 1):
-                got = run(part, m, 12, 0.01, graph=graph, fused_finish=fused, persist=persist, **fixed)
-                assert got.tobytes() == base.tobytes(), (persist, fused, graph)
-    sim = nb.SimPipeline(10000, m)
-    sim.configure(persist=2, **fixed)
-    sim.set_data(part)
-    sim.update(1, 0.01)
-    assert sim.launch_shape()["workgroups"] == (shape["workgroups"] + 1) // 2
-    sim.close()
-
-
-@pytest.mark.parametrize("leg", ["clock probe", "repeats", "extra_configs C2/C3/N2/C1"])
-def test_single_gpu_bench_line_survives_a_leg_that_aborts(leg):
-    """The driver's own command (`python bench.py`, one GPU): every leg after the headline -- clock probe, parity stamp,
-    repeats, the clock-sampler leg, the LDS route, extra_configs -- runs with the line in hand.  A leg that dies by the
-    library's error convention (print + abort(), reference src/lib/util.h:17-29) still leaves the headline on stdout, once,
-    with "extras_aborted" naming the leg, and the run does not report success."""
-    import json
-    env = dict(os.environ, NB_BENCH_REHEARSE=json.dumps({"crash_leg": leg}))
-    r = subprocess.run([sys.executable, os.path.join(nb.ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
-                       env=env, capture_output=True, text=True, timeout=600, cwd=nb.ROOT)
-    assert r.returncode == 6, (r.returncode, r.stderr[-1500:])
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-1000:]
-    out = json.loads(lines[0])
-    assert out["extras_aborted"] == f"{leg} (fatal signal)" and out["value"] > 1e12 and out["roofline"]["frac"] > 0.3
-    assert ("parity" in out) == (leg != "clock probe")      # legs that finished before the abort are on the line
-
-
-def test_single_gpu_bench_skips_the_legs_its_budget_no_longer_holds():
-    """--budget-s bounds the single-GPU run too: with a budget that covers the headline and little else, the optional legs
-    that need more than what is left are LISTED (legs_skipped_for_budget) instead of started, the headline is unaffected, and
-    the run reports success -- a slow box costs legs, never the line."""
-    import json
-    r = subprocess.run([sys.executable, os.path.join(nb.ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--budget-s", "14"],
-                       capture_output=True, text=True, timeout=600, cwd=nb.ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    out = json.loads(lines[0])
-    assert out["value"] > 1e12 and out["roofline"]["frac"] > 0.3 and "extras_aborted" not in out
-    skipped = out["legs_skipped_for_budget"]
-    assert "extra_configs C2/C3/N2/C1" in skipped and "extra_configs S2/S4/S8/C5S8" in skipped
-    assert out.get("extra_configs", []) == []
-
-
-@pytest.mark.parametrize("ranks", [2, 3, 8])
-def test_bench_shard_leg_times_every_ranks_step_and_stamps_it(ranks):
-    """bench.py's S-legs (extra_configs S2 / S4 / S8 / C5S8) at a small size: all shards of one world in this process, every
-    member's kernels under their own HIP event pairs (nb_hip_local_group_step with the timing knob), so the entry says what
-    ONE rank's step costs for every rank, with a parity stamp against float64 and the stated gather estimate."""
-    sys.path.insert(0, nb.ROOT)
-    import bench
-    n = 65536
-    _, part, m = bench_universe(n)
-    one = nb.SimPipeline(n, m)
-    one.configure(graph=0)
-    one.set_data(part)
-    one.update(2, 0.01)
-    t0 = time.perf_counter()
-    one.update(5, 0.01)
-    t1_ms = (time.perf_counter() - t0) / 5 * 1e3
-    one.close()
-    e = bench.shard_leg(nb, f"S{ranks}", part, m, ranks, 3, t1_ms=t1_ms)
-    k = e["shard_kernel_ms_per_step"]
-    assert e["ranks"] == ranks and 0 < k["min"] <= k["mean"] <= k["max"]                 # every member's kernels were timed
-    assert e["single_gpu_ms_per_step"] == t1_ms and e["compute_scaling_efficiency"] > 0  # (how the times relate: test_gpu_zz_perf.py)
-    p = e["parity"]
-    assert p["worst_ratio"] <= 1.0 and p["integrator_bit_exact"] and p["static_fields_equal"], p
-    plan = nb.shard_plan(n, m, 0, ranks)
-    assert abs(e["gather_estimate_ms"] - bench.gather_estimate_ms(plan["mass_chunk"], ranks)) < 1e-12 and "NOT measured" in e["gather_estimate_source"]
-    assert abs(e["predicted_steps_per_sec"] - 1e3 / (k["max"] + e["gather_estimate_ms"])) < 1e-6

@@ -10,7 +10,7 @@ import time
 import pytest
 
 import nbody_amd as nb
-from test_gpu_parity import bench_universe
+from gpu_common import bench_universe
 
 pytestmark = pytest.mark.gpu
 
@@ -100,7 +100,7 @@ def test_clock_sampler_leaves_by_itself_within_its_bound():
 def test_bench_shard_leg_times_relate_to_the_whole_step(ranks):
     """bench.py's S-legs at a small size: a shard's step is shorter than the whole step, not shorter than its share allows,
     and all shards together take about the whole step (the structure and the parity stamp of the entry are checked in
-    test_gpu_parity.py::test_bench_shard_leg_times_every_ranks_step_and_stamps_it)."""
+    test_gpu_harness.py::test_bench_shard_leg_times_every_ranks_step_and_stamps_it)."""
     sys.path.insert(0, nb.ROOT)
     import bench
     n = 65536

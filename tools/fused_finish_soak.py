@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import nbody_amd as nb
-import test_gpu_parity as T
+import gpu_common as T
 
 bad = 0
 def run(part, m, steps, **knobs):

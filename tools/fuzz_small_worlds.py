@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Seeded fuzz of the small-world paths (lane-split launches, the one-workgroup chain, graph vs plain launches) beyond what
-the test suite runs: 480 random worlds x knobs, each checked like tests/test_gpu_parity.py does (one step against float64
+the test suite runs: 480 random worlds x knobs, each checked like the GPU suite does (tests/gpu_common.py) (one step against float64
 with an exact integrator, graph == plain bitwise, several steps against the reference AVX stepper on the displacement
 metric).  Run on the GPU box; prints the failing cases, then the count."""
 import os, sys, numpy as np
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import nbody_amd as nb, oracle_binding as ob
-import test_gpu_parity as T
+import gpu_common as T
 bad = 0
 for block in range(100, 160):
     rng = np.random.default_rng(block)

@@ -10,7 +10,7 @@ grows with M on the AVX side (a sequential fp32 sum of M/8 terms).  For every si
                                 against the float64 sum (which of the two carries the difference);
   K steps, all particles:       rel_displacement = |dpos_gpu - dpos_avx| / |dpos_avx| and relative L2 of the velocities
                                 against the bit-exact AVX restatement stepped K times on the host cores.
-tests/test_gpu_parity.py::test_gpu_versus_the_avx_path_at_every_baseline_size asserts the constants DESIGN.md section 5
+tests/test_gpu_parity.py::test_gpu_versus_the_avx_path_at_every_baseline_size (constants: tests/gpu_common.py GPU_VS_AVX) asserts the constants DESIGN.md section 5
 states from this table.
 """
 import os
