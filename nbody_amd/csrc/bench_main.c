@@ -699,7 +699,7 @@ static int run_ranks(const Options *o) {
         }
         if (!timeout_is_the_users) {
             char buf[32];
-            const double bound = t < last ? (limit > 0.0 && limit * 0.5 < 75.0 ? limit * 0.5 : 75.0) : (limit > 0.0 && limit * 0.8 < 180.0 ? limit * 0.8 : 180.0);
+            const double bound = t < last ? (limit > 0.0 && limit * 0.5 < 120.0 ? limit * 0.5 : 120.0) : (limit > 0.0 && limit * 0.8 < 180.0 ? limit * 0.8 : 180.0);
             snprintf(buf, sizeof buf, "%d", bound < 5.0 ? 5 : (int)bound);
             setenv("NB_HIP_COMM_TIMEOUT_S", buf, 1);
         }

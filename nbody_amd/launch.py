@@ -259,10 +259,11 @@ class Supervisor:
                    NB_BENCH_DEADLINE_MONO=repr(time.monotonic() + limit_s))   # CLOCK_MONOTONIC is one clock for every process of the box
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # the library's own bound on every wait for other ranks (default 180 s) must fit inside the attempt; with a fallback
-        # behind it an attempt does not sit out more than 75 s.  A value the user exported is left alone.
+        # behind it an attempt does not sit out more than 120 s (a cold box pages ~0.5 GB of librccl and its code objects in on
+        # every rank before ncclCommInitRank returns: the bound must not mistake that for a hang).  A value the user exported is left alone.
         if "NB_HIP_COMM_TIMEOUT_S" not in os.environ:
             more = index + 1 < len(self.transports)
-            env["NB_HIP_COMM_TIMEOUT_S"] = str(int(max(5.0, min(75.0 if more else 180.0, limit_s * (0.5 if more else 0.8)))))
+            env["NB_HIP_COMM_TIMEOUT_S"] = str(int(max(5.0, min(120.0 if more else 180.0, limit_s * (0.5 if more else 0.8)))))
         t0 = time.monotonic()
         self.ranks[:] = [RankProcess(self.script, self.passthrough + ["--transport", transport, "--budget-s", repr(limit_s)],
                                      dict(env, RANK=str(r), LOCAL_RANK=str(lr)), r, r == 0) for r, lr in self.local]
