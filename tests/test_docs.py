@@ -6,7 +6,7 @@ import re
 import pytest
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-DOCS = ["STATUS.md", "DESIGN.md", "README.md", "INTEGRATION.md", "profiles/README.md", "tools/README.md"]
+DOCS = ["STATUS.md", "DESIGN.md", "DESIGN_HISTORY.md", "README.md", "INTEGRATION.md", "profiles/README.md", "tools/README.md"]
 PATH = re.compile(r"(?<![A-Za-z0-9_/])((?:profiles|tests|tools|nbody_amd|include|oracle)/[A-Za-z0-9_./-]+\.(?:txt|json|csv|py|sh|hip|c|h|md|err))")
 BARE_PROFILE = re.compile(r"(?<![A-Za-z0-9_/])(r0[1-9]_[A-Za-z0-9_.-]+\.(?:txt|json|csv|err))")
 # named on purpose although gone: the index says so in the same sentence
