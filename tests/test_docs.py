@@ -35,3 +35,19 @@ def test_every_file_a_document_points_at_exists(doc):
 
 def test_status_page_stays_one_page():
     assert len(open(os.path.join(ROOT, "STATUS.md")).read().splitlines()) <= 80
+
+
+@pytest.mark.parametrize("doc", ["STATUS.md", "DESIGN.md", "README.md", "INTEGRATION.md", "profiles/README.md", "include/nbody_hip.h",
+                                 "nbody_amd/csrc/nbody_hip_tuning.h"])
+def test_every_test_a_document_names_exists(doc):
+    """`test_...` names are cited as evidence: each must be a test function of this suite (or an unambiguous prefix of one, for the
+    names the documents shorten), a test module, or the reference's own test file."""
+    import glob
+    names, modules = set(), {"test_particle_sort"}          # the reference's test/test_particle_sort.c
+    for f in glob.glob(os.path.join(ROOT, "tests", "*.py")):
+        modules.add(os.path.basename(f)[:-3])
+        names |= set(re.findall(r"^def (test_[A-Za-z0-9_]+)", open(f).read(), re.M))
+    text = open(os.path.join(ROOT, doc)).read()
+    unknown = {t for t in re.findall(r"(?<![A-Za-z0-9_])(test_[a-z0-9_]+)", text)
+               if t not in modules and t.rstrip("_") not in modules and not any(n.startswith(t.rstrip("_")) for n in names)}
+    assert not unknown, f"{doc} cites tests that do not exist: {sorted(unknown)}"
