@@ -51,3 +51,20 @@ def test_every_test_a_document_names_exists(doc):
     unknown = {t for t in re.findall(r"(?<![A-Za-z0-9_])(test_[a-z0-9_]+)", text)
                if t not in modules and t.rstrip("_") not in modules and not any(n.startswith(t.rstrip("_")) for n in names)}
     assert not unknown, f"{doc} cites tests that do not exist: {sorted(unknown)}"
+
+
+def test_status_headline_table_is_the_drivers_own_record():
+    """STATUS.md's per-round headline rows are copied from the driver's BENCH_rNN.json files: each listed round must match its
+    record (ms/step to 0.1, fraction to 0.001) -- the page quotes the driver, not the builder."""
+    import json
+    text = open(os.path.join(ROOT, "STATUS.md")).read()
+    rows = re.findall(r"^\| r(\d) \| ([0-9.]+) \| ([0-9.]+)·10\^12 \| ([0-9.]+) \|$", text, re.M)
+    assert len(rows) >= 5
+    for rnd, ms, rate, frac in rows:
+        path = os.path.join(ROOT, f"BENCH_r0{rnd}.json")
+        if not os.path.exists(path):
+            pytest.skip(f"{path} not in this checkout")
+        line = json.load(open(path))["parsed"]
+        assert abs(line["ms_per_step"] - float(ms)) < 0.06, (rnd, line["ms_per_step"], ms)
+        assert abs(line["value"] / 1e12 - float(rate)) < 0.006, (rnd, line["value"], rate)
+        assert abs(line["roofline"]["frac"] - float(frac)) < 0.0006, (rnd, line["roofline"]["frac"], frac)
